@@ -1,0 +1,243 @@
+"""ctypes view of include/mi_rtjpeg.h.  No CPU fallback: if the library is missing or there is no
+gfx950 device, construction raises MiRtjError with the library's own message."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+
+
+class MiRtjError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(HERE, "lib", "libmi_rtjpeg.so")
+
+
+EXPORTS = ["mi_rtj_device_count", "mi_rtj_create", "mi_rtj_destroy", "mi_rtj_last_error", "mi_rtj_decode",
+           "mi_rtj_get_state", "mi_rtj_dev_alloc", "mi_rtj_dev_free", "mi_rtj_h2d", "mi_rtj_d2h",
+           "mi_rtj_dev_memset", "mi_rtj_sync", "mi_rtj_plan_create", "mi_rtj_plan_destroy",
+           "mi_rtj_plan_decode", "mi_rtj_plan_info", "mi_rtj_plan_profile", "mi_rtj_plan_times",
+           "mi_rtj_plan_read_index", "mi_rtj_synth_frames", "mi_rtj_encode_bound", "mi_rtj_encode_frames",
+           "mi_rtj_get_tables"]
+
+
+def load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    p = lib_path()
+    if not os.path.exists(p):
+        raise MiRtjError(f"{p} is missing: run `python gmerlin-avdecoder_amd/build.py` (there is no CPU path)")
+    L = C.CDLL(p)
+    vp = C.c_void_p
+    L.mi_rtj_device_count.restype = C.c_int
+    L.mi_rtj_create.argtypes = [C.c_int]
+    L.mi_rtj_create.restype = vp
+    L.mi_rtj_destroy.argtypes = [vp]
+    L.mi_rtj_last_error.argtypes = [vp]
+    L.mi_rtj_last_error.restype = C.c_char_p
+    L.mi_rtj_decode.argtypes = [vp, u8p, C.c_size_t, C.POINTER(u8p), C.POINTER(C.c_int), C.c_int, C.c_int]
+    L.mi_rtj_get_state.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.mi_rtj_dev_alloc.argtypes = [vp, C.c_size_t]
+    L.mi_rtj_dev_alloc.restype = vp
+    L.mi_rtj_dev_free.argtypes = [vp, vp]
+    L.mi_rtj_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+    L.mi_rtj_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    L.mi_rtj_dev_memset.argtypes = [vp, vp, C.c_int, C.c_size_t]
+    L.mi_rtj_sync.argtypes = [vp]
+    L.mi_rtj_plan_create.argtypes = [vp, C.c_int, u8p, u64p, u32p, u64p]
+    L.mi_rtj_plan_create.restype = vp
+    L.mi_rtj_plan_destroy.argtypes = [vp]
+    L.mi_rtj_plan_decode.argtypes = [vp, vp, vp]
+    L.mi_rtj_plan_info.argtypes = [vp, C.POINTER(C.c_int), u64p, u64p, u64p]
+    L.mi_rtj_plan_profile.argtypes = [vp, C.c_int]
+    L.mi_rtj_plan_times.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    L.mi_rtj_plan_read_index.argtypes = [vp, u32p, C.c_size_t]
+    L.mi_rtj_synth_frames.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, vp]
+    L.mi_rtj_encode_bound.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    L.mi_rtj_encode_bound.restype = C.c_size_t
+    L.mi_rtj_encode_frames.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, u64p, u32p]
+    L.mi_rtj_get_tables.argtypes = [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    _LIB = L
+    return L
+
+
+def device_count():
+    return load().mi_rtj_device_count()
+
+
+def get_tables(Q):
+    t = (C.c_int32 * 128)()
+    lb8, cb8 = C.c_int(), C.c_int()
+    rc = load().mi_rtj_get_tables(Q, t, C.byref(lb8), C.byref(cb8))
+    if rc != 0:
+        raise MiRtjError(f"mi_rtj_get_tables({Q}) -> {rc}")
+    a = np.array(t, dtype=np.int32)
+    return a[:64], a[64:], lb8.value, cb8.value
+
+
+class Plan:
+    def __init__(self, owner, handle, n):
+        self.owner, self.h, self.n = owner, handle, n
+
+    def close(self):
+        if self.h:
+            self.owner.L.mi_rtj_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def decode(self, d_stream, d_out):
+        self.owner._chk(self.owner.L.mi_rtj_plan_decode(self.h, d_stream, d_out))
+
+    def info(self):
+        n = C.c_int()
+        nb, bi, bo = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self.owner.L.mi_rtj_plan_info(self.h, C.byref(n), C.byref(nb), C.byref(bi), C.byref(bo))
+        return dict(frames=n.value, blocks=nb.value, bytes_in=bi.value, bytes_out=bo.value)
+
+    def profile(self, on=True):
+        self.owner.L.mi_rtj_plan_profile(self.h, 1 if on else 0)
+
+    def times(self):
+        ms = (C.c_float * 2)()
+        n = C.c_int()
+        self.owner._chk(self.owner.L.mi_rtj_plan_times(self.h, ms, C.byref(n)))
+        return float(ms[0]), float(ms[1]), n.value
+
+    def read_index(self):
+        cnt = self.info()["blocks"] + self.n
+        a = np.zeros(cnt, dtype=np.uint32)
+        self.owner._chk(self.owner.L.mi_rtj_plan_read_index(self.h, a.ctypes.data_as(u32p), cnt))
+        return a
+
+
+class MiRtj:
+    """One decoder instance (== one RTjpeg_t of the reference) bound to one device."""
+
+    def __init__(self, device=-1):
+        self.L = load()
+        self.h = self.L.mi_rtj_create(device)
+        if not self.h:
+            raise MiRtjError("mi_rtj_create failed: " + self.L.mi_rtj_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mi_rtj_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise MiRtjError(f"rc={rc}: " + self.L.mi_rtj_last_error(self.h).decode())
+
+    # -- one packet in, one frame out (decode_rtjpeg) --
+    def decode(self, pkt, out=None, crop=None, strides=None):
+        """pkt: uint8 array.  out: uint8 array receiving Y,U,V back to back (with `strides`, each plane
+        has its own row pitch).  Returns rc-checked None."""
+        pkt = np.ascontiguousarray(pkt, dtype=np.uint8)
+        pp = pkt.ctypes.data_as(u8p)
+        if out is None:
+            self._chk(self.L.mi_rtj_decode(self.h, pp, pkt.size, None, None, 0, 0))
+            return
+        w = int(pkt[6]) | (int(pkt[7]) << 8)
+        h = int(pkt[8]) | (int(pkt[9]) << 8)
+        cw, ch = crop if crop else (w, h)
+        if strides is None:
+            strides = (cw, (cw + 1) // 2, (cw + 1) // 2)
+        ysz = strides[0] * ch
+        csz = strides[1] * ((ch + 1) // 2)
+        assert out.size >= ysz + 2 * csz
+        base = out.ctypes.data
+        planes = (u8p * 3)(C.cast(base, u8p), C.cast(base + ysz, u8p), C.cast(base + ysz + csz, u8p))
+        st = (C.c_int * 3)(*strides)
+        self._chk(self.L.mi_rtj_decode(self.h, pp, pkt.size, planes, st, cw, ch))
+
+    def state(self):
+        w, h, q = C.c_int(), C.c_int(), C.c_int()
+        self.L.mi_rtj_get_state(self.h, C.byref(w), C.byref(h), C.byref(q))
+        return w.value, h.value, q.value
+
+    # -- device memory --
+    def alloc(self, nbytes):
+        p = self.L.mi_rtj_dev_alloc(self.h, nbytes)
+        if not p:
+            raise MiRtjError("alloc failed: " + self.L.mi_rtj_last_error(self.h).decode())
+        return p
+
+    def free(self, p):
+        self.L.mi_rtj_dev_free(self.h, p)
+
+    def h2d(self, dptr, arr, offset=0):
+        arr = np.ascontiguousarray(arr)
+        self._chk(self.L.mi_rtj_h2d(self.h, dptr + offset, arr.ctypes.data, arr.nbytes))
+
+    def d2h(self, dptr, nbytes, offset=0, dtype=np.uint8):
+        a = np.empty(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        self._chk(self.L.mi_rtj_d2h(self.h, a.ctypes.data, dptr + offset, nbytes))
+        return a
+
+    def memset(self, dptr, value, nbytes, offset=0):
+        self._chk(self.L.mi_rtj_dev_memset(self.h, dptr + offset, value, nbytes))
+
+    def sync(self):
+        self._chk(self.L.mi_rtj_sync(self.h))
+
+    # -- batches --
+    def plan(self, headers, pkt_offset, pkt_len, out_offset):
+        headers = np.ascontiguousarray(headers, dtype=np.uint8).reshape(-1)
+        n = headers.size // 12
+        po = np.ascontiguousarray(pkt_offset, dtype=np.uint64)
+        pl = np.ascontiguousarray(pkt_len, dtype=np.uint32)
+        oo = np.ascontiguousarray(out_offset, dtype=np.uint64)
+        assert po.size == n and pl.size == n and oo.size == n
+        h = self.L.mi_rtj_plan_create(self.h, n, headers.ctypes.data_as(u8p), po.ctypes.data_as(u64p),
+                                      pl.ctypes.data_as(u32p), oo.ctypes.data_as(u64p))
+        if not h:
+            raise MiRtjError("plan_create failed: " + self.L.mi_rtj_last_error(self.h).decode())
+        return Plan(self, h, n)
+
+    def upload_packets(self, pkts, align=1):
+        """Host packets -> one device stream buffer.  Returns (dptr, offsets, lens, headers)."""
+        offs, lens, cur = [], [], 0
+        for p in pkts:
+            cur = (cur + align - 1) // align * align
+            offs.append(cur)
+            lens.append(p.size)
+            cur += p.size
+        host = np.zeros(max(cur, 1), dtype=np.uint8)
+        hdrs = np.zeros((len(pkts), 12), dtype=np.uint8)
+        for i, p in enumerate(pkts):
+            host[offs[i]:offs[i] + p.size] = p
+            m = min(12, p.size)
+            hdrs[i, :m] = p[:m]
+        d = self.alloc(host.size)
+        self.h2d(d, host)
+        return d, np.array(offs, np.uint64), np.array(lens, np.uint32), hdrs
+
+    # -- generator side --
+    def synth(self, w, h, first, n, seed=12345, amp=8, dptr=None):
+        fsz = w * h * 3 // 2
+        d = dptr if dptr is not None else self.alloc(fsz * n)
+        self._chk(self.L.mi_rtj_synth_frames(self.h, w, h, first, n, seed, amp, d))
+        return d
+
+    def encode(self, w, h, Q, n, d_frames, align=64):
+        bound = self.L.mi_rtj_encode_bound(w, h, n, align)
+        d_stream = self.alloc(bound)
+        po = np.zeros(n, np.uint64)
+        pl = np.zeros(n, np.uint32)
+        self._chk(self.L.mi_rtj_encode_frames(self.h, w, h, Q, n, d_frames, d_stream, align,
+                                              po.ctypes.data_as(u64p), pl.ctypes.data_as(u32p)))
+        return d_stream, po, pl

@@ -1,0 +1,572 @@
+// mi_rtjpeg.hip — host side of libmi_rtjpeg.so: the C ABI of include/mi_rtjpeg.h over the
+// gfx950 kernels.  No CPU decode path exists here: without a usable device every entry point
+// fails and reports why.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/mi_rtjpeg.h"
+#include "rtj_common.h"
+#include "rtj_decode_kernels.h"
+#include "rtj_encode_kernels.h"
+#include "rtj_tables.h"
+
+using namespace mirtj;
+
+namespace {
+
+constexpr size_t kAllocPad = 256;  // kernels may read a few bytes past a packet's last dword
+
+std::mutex g_err_mu;
+std::string g_create_err = "";
+
+struct Timed {
+  hipEvent_t a = nullptr, b = nullptr;
+};
+
+}  // namespace
+
+struct mi_rtj_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  QTab* d_lut = nullptr;
+  std::string err;
+  // RTjpeg_t's header-driven state (lib/RTjpeg.c:3568-3579)
+  int width = 0, height = 0, Q = 0;
+  // persistent picture of the one-packet path (priv->frame of lib/video_rtjpeg.c:31-35)
+  uint8_t* d_frame = nullptr;
+  size_t frame_bytes = 0;
+  uint8_t* d_pkt = nullptr;
+  size_t pkt_cap = 0;
+  mi_rtj_plan* single = nullptr;  // reusable 1-frame plan
+};
+
+struct mi_rtj_plan {
+  mi_rtj_ctx* ctx = nullptr;
+  int n = 0;
+  std::vector<FrameDev> h_frames;
+  FrameDev* d_frames = nullptr;
+  uint32_t* d_blkoff = nullptr;
+  uint64_t n_blocks = 0, n_index = 0, bytes_in = 0, bytes_out = 0;
+  uint32_t max_groups = 0;
+  bool profile = false;
+  std::vector<Timed> ev_index, ev_decode;  // one pair per launch while profiling
+  int launches = 0;
+};
+
+namespace {
+
+int fail(mi_rtj_ctx* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf;
+  else {
+    std::lock_guard<std::mutex> l(g_err_mu);
+    g_create_err = buf;
+  }
+  return code;
+}
+
+#define HIPCHK(c, call)                                                                       \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess)                                                                     \
+      return fail((c), MI_RTJ_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                                        \
+  } while (0)
+
+bool device_is_gfx950(int dev) {
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, dev) != hipSuccess) return false;
+  return strncmp(p.gcnArchName, "gfx950", 6) == 0;
+}
+
+// RTjpeg_decompress's header handling (lib/RTjpeg.c:3568-3579) on the instance state.
+// Returns the LUT row to use, or a negative error.
+int apply_header(mi_rtj_ctx* c, const uint8_t* hdr, int* w, int* h) {
+  const int hw = hdr[6] | (hdr[7] << 8), hh = hdr[8] | (hdr[9] << 8), q = hdr[10];
+  if (hw <= 0 || hh <= 0 || (hw & 15) || (hh & 15))
+    return fail(c, MI_RTJ_ERR_GEOMETRY, "packet header %dx%d: width and height must be positive multiples of 16", hw, hh);
+  c->width = hw;
+  c->height = hh;
+  if (q != c->Q) c->Q = q < 1 ? 1 : q;  // RTjpeg_set_quality clamps to 1..255 (lib/RTjpeg.c:2410-2411)
+  *w = hw;
+  *h = hh;
+  return c->Q;  // 0 only while no non-zero quality was ever seen: the all-zero tables
+}
+
+int fill_frame(mi_rtj_ctx* c, const uint8_t* hdr, uint64_t pkt_off, uint32_t pkt_len, uint64_t out_off,
+               uint32_t blk_base, FrameDev* f) {
+  int w, h;
+  const int q = apply_header(c, hdr, &w, &h);
+  if (q < 0) return q;
+  if (out_off & 15) return fail(c, MI_RTJ_ERR_ARG, "out_offset %llu is not a multiple of 16", (unsigned long long)out_off);
+  memset(f, 0, sizeof(*f));
+  f->data_off = pkt_off + MI_RTJ_HEADER_SIZE;
+  f->out_off = out_off;
+  f->data_len = pkt_len > MI_RTJ_HEADER_SIZE ? pkt_len - MI_RTJ_HEADER_SIZE : 0;
+  f->w = (uint32_t)w;
+  f->h = (uint32_t)h;
+  f->qidx = (uint32_t)q;
+  f->blk_base = blk_base;
+  f->mbw = (uint32_t)w / 16;
+  f->nmb = f->mbw * ((uint32_t)h / 16);
+  return MI_RTJ_OK;
+}
+
+int plan_upload(mi_rtj_plan* p) {
+  mi_rtj_ctx* c = p->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!p->d_frames) HIPCHK(c, hipMalloc((void**)&p->d_frames, sizeof(FrameDev) * p->n));
+  HIPCHK(c, hipMemcpyAsync(p->d_frames, p->h_frames.data(), sizeof(FrameDev) * p->n, hipMemcpyHostToDevice, c->stream));
+  return MI_RTJ_OK;
+}
+
+int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
+  mi_rtj_ctx* c = p->ctx;
+  Timed ti, td;
+  if (p->profile) {
+    HIPCHK(c, hipEventCreate(&ti.a));
+    HIPCHK(c, hipEventCreate(&ti.b));
+    HIPCHK(c, hipEventCreate(&td.a));
+    HIPCHK(c, hipEventCreate(&td.b));
+    HIPCHK(c, hipEventRecord(ti.a, c->stream));
+  }
+  hipLaunchKernelGGL(k_index_walk, dim3(p->n), dim3(64), 0, c->stream, p->d_frames, (const uint8_t*)d_stream,
+                     c->d_lut, p->d_blkoff);
+  if (p->profile) {
+    HIPCHK(c, hipEventRecord(ti.b, c->stream));
+    HIPCHK(c, hipEventRecord(td.a, c->stream));
+  }
+  hipLaunchKernelGGL(k_decode, dim3(p->max_groups, p->n), dim3(kDecThreads), 0, c->stream, p->d_frames,
+                     (const uint8_t*)d_stream, c->d_lut, p->d_blkoff, (uint8_t*)d_out);
+  if (p->profile) {
+    HIPCHK(c, hipEventRecord(td.b, c->stream));
+    p->ev_index.push_back(ti);
+    p->ev_decode.push_back(td);
+  }
+  HIPCHK(c, hipGetLastError());
+  p->launches++;
+  return MI_RTJ_OK;
+}
+
+void drop_events(std::vector<Timed>& v) {
+  for (auto& t : v) {
+    if (t.a) (void)hipEventDestroy(t.a);
+    if (t.b) (void)hipEventDestroy(t.b);
+  }
+  v.clear();
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_rtj_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int ok = 0;
+  for (int i = 0; i < n; i++) ok += device_is_gfx950(i) ? 1 : 0;
+  return ok;
+}
+
+mi_rtj_ctx* mi_rtj_create(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) {
+    fail(nullptr, MI_RTJ_ERR_NO_DEVICE, "no HIP device: %s — this library has no CPU path", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    return nullptr;
+  }
+  if (device < 0) {
+    if (hipGetDevice(&device) != hipSuccess) device = 0;
+  }
+  if (device >= n) {
+    fail(nullptr, MI_RTJ_ERR_ARG, "device %d out of range (%d devices)", device, n);
+    return nullptr;
+  }
+  if (!device_is_gfx950(device)) {
+    hipDeviceProp_t p;
+    (void)hipGetDeviceProperties(&p, device);
+    fail(nullptr, MI_RTJ_ERR_NO_DEVICE, "device %d is %s; the kernels are built for gfx950 only", device, p.gcnArchName);
+    return nullptr;
+  }
+  mi_rtj_ctx* c = new mi_rtj_ctx();
+  c->device = device;
+  auto bail = [&](const char* what, hipError_t err) -> mi_rtj_ctx* {
+    fail(nullptr, MI_RTJ_ERR_HIP, "%s: %s", what, hipGetErrorString(err));
+    mi_rtj_destroy(c);
+    return nullptr;
+  };
+  if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+  std::vector<QTab> lut(kNumQTab);
+  build_all_qtabs(lut.data());
+  if ((e = hipMalloc((void**)&c->d_lut, sizeof(QTab) * kNumQTab)) != hipSuccess) return bail("hipMalloc(lut)", e);
+  if ((e = hipMemcpy(c->d_lut, lut.data(), sizeof(QTab) * kNumQTab, hipMemcpyHostToDevice)) != hipSuccess)
+    return bail("hipMemcpy(lut)", e);
+  return c;
+}
+
+void mi_rtj_destroy(mi_rtj_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->single) mi_rtj_plan_destroy(c->single);
+  if (c->d_frame) (void)hipFree(c->d_frame);
+  if (c->d_pkt) (void)hipFree(c->d_pkt);
+  if (c->d_lut) (void)hipFree(c->d_lut);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* mi_rtj_last_error(const mi_rtj_ctx* c) {
+  if (c) return c->err.c_str();
+  std::lock_guard<std::mutex> l(g_err_mu);
+  static thread_local std::string copy;
+  copy = g_create_err;
+  return copy.c_str();
+}
+
+void mi_rtj_get_state(const mi_rtj_ctx* c, int* w, int* h, int* q) {
+  if (!c) return;
+  if (w) *w = c->width;
+  if (h) *h = c->height;
+  if (q) *q = c->Q;
+}
+
+void* mi_rtj_dev_alloc(mi_rtj_ctx* c, size_t bytes) {
+  if (!c) return nullptr;
+  void* p = nullptr;
+  if (hipSetDevice(c->device) != hipSuccess) return nullptr;
+  hipError_t e = hipMalloc(&p, bytes + kAllocPad);
+  if (e != hipSuccess) {
+    fail(c, MI_RTJ_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return nullptr;
+  }
+  // the tail pad is read (never used) by dword-granular staging; keep it defined
+  (void)hipMemsetAsync((uint8_t*)p + bytes, 0, kAllocPad, c->stream);
+  return p;
+}
+
+void mi_rtj_dev_free(mi_rtj_ctx* c, void* d) {
+  if (!c || !d) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipFree(d);
+}
+
+int mi_rtj_h2d(mi_rtj_ctx* c, void* d, const void* s, size_t n) {
+  if (!c || (!d && n) || (!s && n)) return fail(c, MI_RTJ_ERR_ARG, "mi_rtj_h2d: NULL argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MI_RTJ_OK;
+}
+
+int mi_rtj_d2h(mi_rtj_ctx* c, void* dst, const void* d, size_t n) {
+  if (!c || (!d && n) || (!dst && n)) return fail(c, MI_RTJ_ERR_ARG, "mi_rtj_d2h: NULL argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(dst, d, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MI_RTJ_OK;
+}
+
+int mi_rtj_dev_memset(mi_rtj_ctx* c, void* d, int v, size_t n) {
+  if (!c || (!d && n)) return fail(c, MI_RTJ_ERR_ARG, "mi_rtj_dev_memset: NULL argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemsetAsync(d, v, n, c->stream));
+  return MI_RTJ_OK;
+}
+
+int mi_rtj_sync(mi_rtj_ctx* c) {
+  if (!c) return MI_RTJ_ERR_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MI_RTJ_OK;
+}
+
+mi_rtj_plan* mi_rtj_plan_create(mi_rtj_ctx* c, int n, const uint8_t* headers, const uint64_t* pkt_offset,
+                                const uint32_t* pkt_len, const uint64_t* out_offset) {
+  if (!c || n <= 0 || !headers || !pkt_offset || !pkt_len || !out_offset) {
+    fail(c, MI_RTJ_ERR_ARG, "mi_rtj_plan_create: bad argument");
+    return nullptr;
+  }
+  mi_rtj_plan* p = new mi_rtj_plan();
+  p->ctx = c;
+  p->n = n;
+  p->h_frames.resize(n);
+  uint64_t blk_base = 0;
+  for (int i = 0; i < n; i++) {
+    if (blk_base > 0xFFFFFFFFull - (1u << 24)) {
+      fail(c, MI_RTJ_ERR_ARG, "plan too large: block index exceeds 32 bits");
+      delete p;
+      return nullptr;
+    }
+    if (fill_frame(c, headers + (size_t)i * MI_RTJ_HEADER_SIZE, pkt_offset[i], pkt_len[i], out_offset[i],
+                   (uint32_t)blk_base, &p->h_frames[i]) != MI_RTJ_OK) {
+      delete p;
+      return nullptr;
+    }
+    const FrameDev& f = p->h_frames[i];
+    const uint64_t nblk = (uint64_t)f.nmb * 6;
+    p->n_blocks += nblk;
+    blk_base += (nblk + 1 + 63) & ~63ull;  // keep every frame's index 256-byte aligned
+    p->bytes_in += pkt_len[i];
+    p->bytes_out += (uint64_t)f.w * f.h * 3 / 2;
+    const uint32_t groups = (f.nmb + kMbPerGroup - 1) / kMbPerGroup;
+    if (groups > p->max_groups) p->max_groups = groups;
+  }
+  p->n_index = blk_base;
+  if (hipSetDevice(c->device) != hipSuccess ||
+      hipMalloc((void**)&p->d_blkoff, sizeof(uint32_t) * p->n_index) != hipSuccess) {
+    fail(c, MI_RTJ_ERR_NOMEM, "hipMalloc(block index, %llu entries) failed", (unsigned long long)p->n_index);
+    delete p;
+    return nullptr;
+  }
+  if (plan_upload(p) != MI_RTJ_OK) {
+    mi_rtj_plan_destroy(p);
+    return nullptr;
+  }
+  return p;
+}
+
+void mi_rtj_plan_destroy(mi_rtj_plan* p) {
+  if (!p) return;
+  (void)hipSetDevice(p->ctx->device);
+  (void)hipStreamSynchronize(p->ctx->stream);
+  drop_events(p->ev_index);
+  drop_events(p->ev_decode);
+  if (p->d_frames) (void)hipFree(p->d_frames);
+  if (p->d_blkoff) (void)hipFree(p->d_blkoff);
+  delete p;
+}
+
+int mi_rtj_plan_decode(mi_rtj_plan* p, const void* d_stream, void* d_out) {
+  if (!p || !d_stream || !d_out) return fail(p ? p->ctx : nullptr, MI_RTJ_ERR_ARG, "mi_rtj_plan_decode: NULL argument");
+  HIPCHK(p->ctx, hipSetDevice(p->ctx->device));
+  return plan_launch(p, d_stream, d_out);
+}
+
+void mi_rtj_plan_info(const mi_rtj_plan* p, int* n, uint64_t* nb, uint64_t* bi, uint64_t* bo) {
+  if (!p) return;
+  if (n) *n = p->n;
+  if (nb) *nb = p->n_blocks;
+  if (bi) *bi = p->bytes_in;
+  if (bo) *bo = p->bytes_out;
+}
+
+void mi_rtj_plan_profile(mi_rtj_plan* p, int enable) {
+  if (!p) return;
+  (void)hipStreamSynchronize(p->ctx->stream);
+  drop_events(p->ev_index);
+  drop_events(p->ev_decode);
+  p->profile = enable != 0;
+  p->launches = 0;
+}
+
+int mi_rtj_plan_times(mi_rtj_plan* p, float ms[2], int* launches) {
+  if (!p || !ms) return MI_RTJ_ERR_ARG;
+  mi_rtj_ctx* c = p->ctx;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  ms[0] = ms[1] = 0.f;
+  for (auto& t : p->ev_index) {
+    float x = 0;
+    HIPCHK(c, hipEventElapsedTime(&x, t.a, t.b));
+    ms[0] += x;
+  }
+  for (auto& t : p->ev_decode) {
+    float x = 0;
+    HIPCHK(c, hipEventElapsedTime(&x, t.a, t.b));
+    ms[1] += x;
+  }
+  if (launches) *launches = (int)p->ev_index.size();
+  return MI_RTJ_OK;
+}
+
+int mi_rtj_plan_read_index(mi_rtj_plan* p, uint32_t* dst, size_t max_entries) {
+  if (!p || !dst) return MI_RTJ_ERR_ARG;
+  mi_rtj_ctx* c = p->ctx;
+  std::vector<uint32_t> all(p->n_index);
+  HIPCHK(c, hipMemcpyAsync(all.data(), p->d_blkoff, sizeof(uint32_t) * p->n_index, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  size_t k = 0;
+  for (int i = 0; i < p->n; i++) {
+    const FrameDev& f = p->h_frames[i];
+    const size_t cnt = (size_t)f.nmb * 6 + 1;
+    if (k + cnt > max_entries) return fail(c, MI_RTJ_ERR_ARG, "mi_rtj_plan_read_index: destination too small");
+    memcpy(dst + k, all.data() + f.blk_base, cnt * sizeof(uint32_t));
+    k += cnt;
+  }
+  return MI_RTJ_OK;
+}
+
+int mi_rtj_decode(mi_rtj_ctx* c, const uint8_t* pkt, size_t len, uint8_t* const dst[3], const int dst_stride[3],
+                  int crop_w, int crop_h) {
+  if (!c || !pkt) return fail(c, MI_RTJ_ERR_ARG, "mi_rtj_decode: NULL argument");
+  if (len < MI_RTJ_HEADER_SIZE) return fail(c, MI_RTJ_ERR_ARG, "mi_rtj_decode: packet shorter than its %d-byte header", MI_RTJ_HEADER_SIZE);
+  HIPCHK(c, hipSetDevice(c->device));
+  // plan of one frame, rebuilt per packet (its header may change size or quality)
+  if (!c->single) {
+    c->single = new mi_rtj_plan();
+    c->single->ctx = c;
+    c->single->n = 1;
+    c->single->h_frames.resize(1);
+  }
+  mi_rtj_plan* p = c->single;
+  const int rc = fill_frame(c, pkt, 0, (uint32_t)len, 0, 0, &p->h_frames[0]);
+  if (rc != MI_RTJ_OK) return rc;
+  const FrameDev& f = p->h_frames[0];
+  const size_t need_frame = (size_t)f.w * f.h * 3 / 2;
+  if (need_frame > c->frame_bytes) {  // gavl_video_frame_create in init_rtjpeg (lib/video_rtjpeg.c:54)
+    uint8_t* nf = nullptr;
+    HIPCHK(c, hipMalloc((void**)&nf, need_frame + kAllocPad));
+    HIPCHK(c, hipMemsetAsync(nf, 0, need_frame + kAllocPad, c->stream));
+    if (c->d_frame) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      (void)hipFree(c->d_frame);
+    }
+    c->d_frame = nf;
+    c->frame_bytes = need_frame;
+  }
+  if (len + kAllocPad > c->pkt_cap) {
+    if (c->d_pkt) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      (void)hipFree(c->d_pkt);
+      c->d_pkt = nullptr;
+    }
+    c->pkt_cap = (len + kAllocPad) * 2;
+    HIPCHK(c, hipMalloc((void**)&c->d_pkt, c->pkt_cap));
+  }
+  const uint64_t nidx = (((uint64_t)f.nmb * 6 + 1) + 63) & ~63ull;
+  if (nidx > p->n_index) {
+    if (p->d_blkoff) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      (void)hipFree(p->d_blkoff);
+      p->d_blkoff = nullptr;
+    }
+    HIPCHK(c, hipMalloc((void**)&p->d_blkoff, sizeof(uint32_t) * nidx));
+    p->n_index = nidx;
+  }
+  p->n_blocks = (uint64_t)f.nmb * 6;
+  p->max_groups = (f.nmb + kMbPerGroup - 1) / kMbPerGroup;
+  HIPCHK(c, hipMemcpyAsync(c->d_pkt, pkt, len, hipMemcpyHostToDevice, c->stream));
+  int r = plan_upload(p);
+  if (r != MI_RTJ_OK) return r;
+  r = plan_launch(p, c->d_pkt, c->d_frame);
+  if (r != MI_RTJ_OK) return r;
+  if (dst) {
+    // gavl_video_frame_copy(format, f, priv->frame) (lib/video_rtjpeg.c:82): image_width x
+    // image_height region, each side's own strides — done by the copy engine on the way out.
+    if (!dst[0] || !dst[1] || !dst[2] || !dst_stride) return fail(c, MI_RTJ_ERR_ARG, "mi_rtj_decode: NULL plane");
+    if (crop_w <= 0 || crop_h <= 0 || crop_w > (int)f.w || crop_h > (int)f.h)
+      return fail(c, MI_RTJ_ERR_ARG, "mi_rtj_decode: crop %dx%d outside the coded %ux%u picture", crop_w, crop_h, f.w, f.h);
+    const size_t ysz = (size_t)f.w * f.h;
+    const int cw = (crop_w + 1) / 2, ch = (crop_h + 1) / 2;
+    HIPCHK(c, hipMemcpy2DAsync(dst[0], (size_t)dst_stride[0], c->d_frame, f.w, (size_t)crop_w, (size_t)crop_h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(dst[1], (size_t)dst_stride[1], c->d_frame + ysz, f.w / 2, (size_t)cw, (size_t)ch, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpy2DAsync(dst[2], (size_t)dst_stride[2], c->d_frame + ysz + ysz / 4, f.w / 2, (size_t)cw, (size_t)ch, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MI_RTJ_OK;
+}
+
+int mi_rtj_synth_frames(mi_rtj_ctx* c, int w, int h, int first, int n, uint32_t seed, int amp, void* d_frames) {
+  if (!c || !d_frames || w <= 0 || h <= 0 || (w & 15) || (h & 15) || n <= 0 || amp < 0)
+    return fail(c, MI_RTJ_ERR_ARG, "mi_rtj_synth_frames: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_synth, dim3(1024, n), dim3(256), 0, c->stream, (uint8_t*)d_frames, w, h, first, seed, amp);
+  HIPCHK(c, hipGetLastError());
+  return MI_RTJ_OK;
+}
+
+size_t mi_rtj_encode_bound(int w, int h, int n, int align) {
+  if (w <= 0 || h <= 0 || n <= 0 || align < 1) return 0;
+  const size_t per = MI_RTJ_HEADER_SIZE + (size_t)(w / 16) * (h / 16) * 6 * 64;
+  return (size_t)n * ((per + align - 1) / align * align) + align;
+}
+
+int mi_rtj_encode_frames(mi_rtj_ctx* c, int w, int h, int Q, int n, const void* d_frames, void* d_stream, int align,
+                         uint64_t* pkt_offset, uint32_t* pkt_len) {
+  if (!c || !d_frames || !d_stream || !pkt_offset || !pkt_len || w <= 0 || h <= 0 || (w & 15) || (h & 15) ||
+      n <= 0 || align < 1 || (align & (align - 1)))
+    return fail(c, MI_RTJ_ERR_ARG, "mi_rtj_encode_frames: bad argument");
+  if (Q < 1) Q = 1;
+  if (Q > 255) Q = 255;
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint32_t nblk = (uint32_t)(w / 16) * (h / 16) * 6;
+  const size_t fsz = (size_t)w * h * 3 / 2;
+  const int chunk = 32;  // frames per pass: bounds the 64-byte-per-block scratch
+  uint8_t *slots = nullptr, *lens = nullptr;
+  uint32_t *offs = nullptr, *fbytes = nullptr;
+  uint64_t* d_pktoff = nullptr;
+  int rc = MI_RTJ_OK;
+  auto cleanup = [&]() {
+    (void)hipStreamSynchronize(c->stream);
+    if (slots) (void)hipFree(slots);
+    if (lens) (void)hipFree(lens);
+    if (offs) (void)hipFree(offs);
+    if (fbytes) (void)hipFree(fbytes);
+    if (d_pktoff) (void)hipFree(d_pktoff);
+  };
+#define ENC_CHK(call)                                                                                         \
+  do {                                                                                                        \
+    hipError_t e_ = (call);                                                                                   \
+    if (e_ != hipSuccess) {                                                                                   \
+      rc = fail(c, MI_RTJ_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      cleanup();                                                                                              \
+      return rc;                                                                                              \
+    }                                                                                                         \
+  } while (0)
+  ENC_CHK(hipMalloc((void**)&slots, (size_t)chunk * nblk * 64));
+  ENC_CHK(hipMalloc((void**)&lens, (size_t)chunk * nblk));
+  ENC_CHK(hipMalloc((void**)&offs, (size_t)chunk * nblk * 4));
+  ENC_CHK(hipMalloc((void**)&fbytes, (size_t)chunk * 4));
+  ENC_CHK(hipMalloc((void**)&d_pktoff, (size_t)chunk * 8));
+  std::vector<uint32_t> hb(chunk);
+  uint64_t cursor = 0;
+  for (int f0 = 0; f0 < n; f0 += chunk) {
+    const int m = n - f0 < chunk ? n - f0 : chunk;
+    const size_t tot = (size_t)m * nblk;
+    hipLaunchKernelGGL(k_encode_blocks, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
+                       (const uint8_t*)d_frames + (size_t)f0 * fsz, w, h, m, c->d_lut + Q, slots, lens);
+    hipLaunchKernelGGL(k_encode_scan, dim3(m), dim3(256), 0, c->stream, lens, nblk, offs, fbytes);
+    ENC_CHK(hipMemcpyAsync(hb.data(), fbytes, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
+    ENC_CHK(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < m; i++) {
+      cursor = (cursor + align - 1) / align * align;
+      pkt_offset[f0 + i] = cursor;
+      pkt_len[f0 + i] = hb[i] + MI_RTJ_HEADER_SIZE;
+      cursor += pkt_len[f0 + i];
+    }
+    ENC_CHK(hipMemcpyAsync(d_pktoff, pkt_offset + f0, (size_t)m * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_encode_pack, dim3((nblk + 255) / 256, m), dim3(256), 0, c->stream, slots, lens, offs,
+                       d_pktoff, fbytes, nblk, w, h, Q, (uint8_t*)d_stream);
+    ENC_CHK(hipGetLastError());
+    ENC_CHK(hipStreamSynchronize(c->stream));
+  }
+#undef ENC_CHK
+  cleanup();
+  return MI_RTJ_OK;
+}
+
+int mi_rtj_get_tables(int Q, int32_t tables[128], int* lb8, int* cb8) {
+  if (!tables || Q < 1 || Q > 255) return MI_RTJ_ERR_ARG;
+  QTab t;
+  build_qtab(Q, &t);
+  memcpy(tables, t.liqt, sizeof t.liqt);
+  memcpy(tables + 64, t.ciqt, sizeof t.ciqt);
+  if (lb8) *lb8 = t.lb8;
+  if (cb8) *cb8 = t.cb8;
+  return MI_RTJ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,316 @@
+// rtj_decode_kernels.h — gfx950 kernels of the RTjpeg decode path.
+//
+//   k_index_walk   block-start index of every packet: RTjpeg_s2b's length rule
+//                  (lib/RTjpeg.c:157-186) driven by RTjpeg_decompressYUV420's block order
+//                  (lib/RTjpeg.c:2688-2749).
+//   k_decode       dequantise + 8x8 AAN inverse transform + plane scatter
+//                  (lib/RTjpeg.c:157-186, 2209-2332, 2688-2749), one lane per 8x8 block.
+//
+// Integer only; no MFMA: the transform is a fixed 8-point butterfly network with rounding
+// after every product, not a contraction.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rtj_common.h"
+
+namespace mirtj {
+
+__constant__ uint8_t c_zz[64] = MIRTJ_ZZ_INIT;
+
+// ---------------------------------------------------------------------------------------
+// wave64 inclusive prefix sum with DPP row shifts + row broadcasts (no LDS)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+#ifdef MIRTJ_SCAN_SHFL
+  const int lane = threadIdx.x & 63;
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(x, d);
+    if (lane >= d) x += t;
+  }
+  return x;
+#else
+  // within each row of 16 lanes: Hillis-Steele with row_shr 1,2,4,8 (out-of-row sources read 0)
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);
+  // lane 15 of rows 0 and 2 into every lane of rows 1 and 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);
+  // lane 31 into every lane of rows 2 and 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);
+  return x;
+#endif
+}
+
+// number of coefficient slots a stream byte covers when it is read as a token (lib/RTjpeg.c:171-182):
+// 64..127 (int8 > 63) is a zero run of b-63, anything else is one coefficient
+__device__ __forceinline__ uint32_t token_weight(uint32_t b) {
+  return (b - 64u < 64u) ? b - 63u : 1u;
+}
+
+// ---------------------------------------------------------------------------------------
+// k_index_walk: one wave per packet walks the block chain.
+//
+// Lane i of the wave holds byte base+i of the stream (two 64-byte windows, "cur" and "nxt")
+// and the running sum W of token weights.  A block that starts at p with bt8 raw bytes ends at
+// the first byte e whose W reaches W[p+bt8] + (63-bt8): one compare + find-first-set per block.
+// The chain itself is serial (a block's length is only known once it has been read), so the
+// position lives in scalar registers and the vector unit is used 64 bytes at a time.
+// Output: byte offset of every block start relative to the first data byte, nblk+1 entries.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_index_walk(const FrameDev* __restrict__ frames,
+                                                    const uint8_t* __restrict__ stream,
+                                                    const QTab* __restrict__ lut,
+                                                    uint32_t* __restrict__ blkoff) {
+  const FrameDev f = frames[blockIdx.x];
+  const int lane = threadIdx.x;
+  const uint8_t* g = stream + f.data_off;
+  const uint32_t len = f.data_len;
+  const uint32_t nblk = f.nmb * 6u;
+  const uint32_t lb8 = (uint32_t)lut[f.qidx].lb8, cb8 = (uint32_t)lut[f.qidx].cb8;
+  uint32_t* out = blkoff + f.blk_base;
+
+  auto fetch = [&](uint32_t pos) -> uint32_t {
+    const uint32_t i = pos + lane;
+    return i < len ? (uint32_t)g[i] : 0u;
+  };
+
+  uint32_t base = 0;
+  uint32_t cur = fetch(0), nxt = fetch(64), pf1 = fetch(128), pf2 = fetch(192), pf3 = fetch(256);
+  uint32_t Wc = wave_incl_scan(token_weight(cur));
+  uint32_t Wn = wave_incl_scan(token_weight(nxt)) + (uint32_t)__builtin_amdgcn_readlane((int)Wc, 63);
+
+  uint32_t p = 0;       // current block start (uniform)
+  uint32_t ph = 0;      // block number within the macroblock, 0..5
+  uint32_t acc = 0;     // 64 offsets gathered one lane at a time, stored 256 B at once
+
+  for (uint32_t k = 0;; ++k) {
+    while (p - base >= 64u) {  // slide the two windows forward
+      base += 64u;
+      cur = nxt;
+      Wc = Wn;
+      nxt = pf1;
+      pf1 = pf2;
+      pf2 = pf3;
+      pf3 = fetch(base + 256u);
+      Wn = wave_incl_scan(token_weight(nxt)) + (uint32_t)__builtin_amdgcn_readlane((int)Wc, 63);
+    }
+    acc = (uint32_t)lane == (k & 63u) ? p : acc;
+    if ((k & 63u) == 63u) out[(k & ~63u) + lane] = acc;
+    if (k == nblk) break;
+
+    const uint32_t lp = p - base;
+    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)lp);
+    const uint32_t bt8 = ph >= 4u ? cb8 : lb8;
+    ph = ph == 5u ? 0u : ph + 1u;
+    if (b0 == 0xFFu) {  // "unchanged" block: a single byte
+      p += 1u;
+      continue;
+    }
+    const uint32_t need = 63u - bt8;
+    if (need == 0u) {  // every coefficient is a raw byte
+      p += 64u;
+      continue;
+    }
+    const uint32_t iq = lp + bt8;  // last non-token byte of the block, 0..126
+    const uint32_t Wq = iq < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)Wc, (int)iq)
+                                 : (uint32_t)__builtin_amdgcn_readlane((int)Wn, (int)(iq - 64u));
+    const uint32_t target = Wq + need;
+    const unsigned long long mc = __ballot(Wc >= target);
+    uint32_t e;
+    if (mc) {
+      e = (uint32_t)__builtin_ctzll(mc);
+    } else {
+      const unsigned long long mn = __ballot(Wn >= target);
+      e = 64u + (uint32_t)__builtin_ctzll(mn);  // W grows by >= 1 per byte, so mn != 0
+    }
+    p = base + e + 1u;
+  }
+  if ((nblk & 63u) != 63u && (uint32_t)lane <= (nblk & 63u)) out[(nblk & ~63u) + lane] = acc;
+}
+
+// ---------------------------------------------------------------------------------------
+// 8-point inverse AAN butterfly (lib/RTjpeg.c:2240-2283 for columns, :2290-2327 for rows;
+// constants :1196-1199, MULTIPLY :1206).  Every multiplicand stays below 2^23 in magnitude
+// for any int16 input block (tests/test_bounds.py), so the 24-bit multiplier is exact and
+// wraps like the reference's 32-bit product.
+// ---------------------------------------------------------------------------------------
+// v_mad_i32_i24 is spelled out: hipcc's value tracking cannot see the 2^23 bound and would
+// otherwise fall back to the quarter-rate 32-bit multiplier for the whole row pass.
+__device__ __forceinline__ int mulr8(int x, int c) {
+  int r;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(c), "v"(128));
+  return r >> 8;
+}
+
+__device__ __forceinline__ void idct8(int x0, int x1, int x2, int x3, int x4, int x5, int x6, int x7,
+                                      int (&y)[8]) {
+  const int s04 = x0 + x4, d04 = x0 - x4;
+  const int s26 = x2 + x6;
+  const int r26 = mulr8(x2 - x6, 362) - s26;
+  const int e0 = s04 + s26, e3 = s04 - s26, e1 = d04 + r26, e2 = d04 - r26;
+  const int s53 = x5 + x3, d53 = x5 - x3, s17 = x1 + x7, d17 = x1 - x7;
+  const int o7 = s17 + s53;
+  const int m = mulr8(s17 - s53, 362);
+  const int z5 = mulr8(d53 + d17, 473);
+  const int o6 = mulr8(d53, -669) + z5 - o7;
+  const int o5 = m - o6;
+  const int o4 = mulr8(d17, 277) - z5 + o5;
+  y[0] = e0 + o7; y[7] = e0 - o7;
+  y[1] = e1 + o6; y[6] = e1 - o6;
+  y[2] = e2 + o5; y[5] = e2 - o5;
+  y[4] = e3 + o4; y[3] = e3 - o4;
+}
+
+// DESCALE + int16 narrowing + clamp 16..235 (lib/RTjpeg.c:1201-1205).  The +4 rounding term
+// was folded into the DC coefficient before the column pass, so only the shift remains:
+// bits [18:3] sign-extended == (int16_t)(v >> 3).
+__device__ __forceinline__ uint32_t px(int v) {
+  int s = (int)((uint32_t)v << 13) >> 16;
+  s = s > 235 ? 235 : s;
+  s = s < 16 ? 16 : s;
+  return (uint32_t)s;
+}
+
+constexpr int kDecThreads = 192;
+constexpr int kCoefStride = 72;                 // int16 per lane: 64 + 8 pad (144 B, conflict-free b128 reads)
+constexpr int kStreamCap = kMbPerGroup * 6 * 64; // worst-case bytes of one macroblock group
+
+// ---------------------------------------------------------------------------------------
+// k_decode: grid (groups, frames); a workgroup owns kMbPerGroup consecutive macroblocks.
+//   wave 0: the 64 upper luma blocks (Y0,Y1 of each MB), wave 1: the 64 lower ones,
+//   wave 2: 32 Cb + 32 Cr blocks.  Lanes of a wave hold horizontally adjacent blocks, so
+//   every row store of a wave covers 512 (luma) or 2x256 (chroma) contiguous bytes.
+// The group's slice of the stream is staged in LDS, each lane parses its own block into a
+// private LDS scratch (transposed, so a column is one 16-byte read), then runs both
+// transform passes entirely in registers.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kDecThreads) void k_decode(const FrameDev* __restrict__ frames,
+                                                         const uint8_t* __restrict__ stream,
+                                                         const QTab* __restrict__ lut,
+                                                         const uint32_t* __restrict__ blkoff,
+                                                         uint8_t* __restrict__ outbuf) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_stream[kStreamCap / 4 + 4];
+  __shared__ __attribute__((aligned(16))) int16_t s_coef[kDecThreads * kCoefStride];
+  __shared__ uint32_t s_tab[2][64];  // per zig-zag slot: (dequantiser << 8) | transposed position
+
+  const FrameDev f = frames[blockIdx.y];
+  const uint32_t mb0 = blockIdx.x * kMbPerGroup;
+  if (mb0 >= f.nmb) return;
+  const int tid = threadIdx.x;
+  const uint32_t mb_end = min(mb0 + (uint32_t)kMbPerGroup, f.nmb);
+  const uint32_t* off = blkoff + f.blk_base;
+  const QTab& qt = lut[f.qidx];
+
+  if (tid < 128) {
+    const int t = tid >> 6, co = tid & 63;
+    const int nat = c_zz[co];
+    const int q = t ? qt.ciqt[nat] : qt.liqt[nat];
+    s_tab[t][co] = ((uint32_t)q << 8) | (uint32_t)((nat & 7) * 8 + (nat >> 3));
+  }
+
+  // ---- stage the group's bytes: [start, end) relative to the first data byte ----
+  const uint32_t start = off[6u * mb0], end = off[6u * mb_end];
+  const uint8_t* gsrc = stream + f.data_off + start;
+  const uint32_t mis = (uint32_t)((uintptr_t)gsrc & 3u);
+  const uint32_t* g4 = (const uint32_t*)(gsrc - mis);
+  const uint32_t ndw = (end - start + mis + 3u) >> 2;
+  for (uint32_t j = tid; j < ndw; j += kDecThreads) {
+    const long long rel = (long long)start - (long long)mis + 4ll * j;  // of the dword's first byte
+    uint32_t v = 0;
+    if (rel < (long long)f.data_len) {
+      v = g4[j];
+      const long long rem = (long long)f.data_len - rel;
+      if (rem < 4) v &= (1u << (8 * (int)rem)) - 1u;  // bytes at or past the end read as 0
+    }
+    s_stream[j] = v;
+  }
+  __syncthreads();
+
+  // ---- which block is mine ----
+  const int wv = tid >> 6, lane = tid & 63;
+  uint32_t mb, kblk;
+  if (wv < 2) {
+    mb = mb0 + (lane >> 1);
+    kblk = 2u * wv + (lane & 1);
+  } else {
+    mb = mb0 + (lane & 31);
+    kblk = 4u + (lane >> 5);
+  }
+  if (mb >= mb_end) return;  // no barriers below
+  const int chroma = kblk >= 4u;
+  const uint32_t bt8 = (uint32_t)(chroma ? qt.cb8 : qt.lb8);
+  const uint8_t* sb = (const uint8_t*)s_stream + mis;
+  uint32_t ci = off[6u * mb + kblk] - start;
+  const uint32_t b0 = sb[ci++];
+  if (b0 == 0xFFu) return;  // unchanged block: previous pixels stay (lib/RTjpeg.c:2704)
+
+  // ---- stream -> dequantised coefficients, int16, transposed (lib/RTjpeg.c:157-186) ----
+  int16_t* my = s_coef + tid * kCoefStride;
+  {
+    uint4* z = (uint4*)my;
+#pragma unroll
+    for (int i = 0; i < 8; i++) z[i] = make_uint4(0, 0, 0, 0);
+  }
+  const uint32_t* tab = s_tab[chroma];
+  {
+    const uint32_t e = tab[0];
+    my[e & 63u] = (int16_t)(b0 * (e >> 8));  // DC is the only unsigned byte
+  }
+  uint32_t co = 1;
+  for (; co <= bt8; co++) {
+    const int v = (int8_t)sb[ci++];
+    const uint32_t e = tab[co];
+    my[e & 63u] = (int16_t)(v * (int)(e >> 8));
+  }
+  while (co < 64u) {
+    const int v = (int8_t)sb[ci++];
+    if (v > 63) {
+      co += (uint32_t)(v - 63);  // zero run; the scratch is already zero
+    } else {
+      const uint32_t e = tab[co];
+      my[e & 63u] = (int16_t)(v * (int)(e >> 8));
+      co++;
+    }
+  }
+
+  // ---- column pass: column c of the block is the c-th 16-byte piece of the scratch ----
+  int ws[8][8];
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    const uint4 q = ((const uint4*)my)[c];
+    int x0 = (int)(int16_t)(q.x & 0xFFFFu), x1 = (int)q.x >> 16;
+    const int x2 = (int)(int16_t)(q.y & 0xFFFFu), x3 = (int)q.y >> 16;
+    const int x4 = (int)(int16_t)(q.z & 0xFFFFu), x5 = (int)q.z >> 16;
+    const int x6 = (int)(int16_t)(q.w & 0xFFFFu), x7 = (int)q.w >> 16;
+    if (c == 0) x0 += 4;  // DESCALE's rounding term, carried through both linear DC paths
+    int y[8];
+    idct8(x0, x1, x2, x3, x4, x5, x6, x7, y);
+#pragma unroll
+    for (int r = 0; r < 8; r++) ws[r][c] = y[r];
+  }
+
+  // ---- row pass + scatter ----
+  const uint32_t mx = mb % f.mbw, my_ = mb / f.mbw;
+  uint8_t* dst;
+  uint32_t stride;
+  if (!chroma) {
+    stride = f.w;
+    dst = outbuf + f.out_off + (size_t)(16u * my_ + 8u * (kblk >> 1)) * stride + 16u * mx + 8u * (kblk & 1u);
+  } else {
+    stride = f.w >> 1;
+    const size_t ysz = (size_t)f.w * f.h;
+    dst = outbuf + f.out_off + ysz + (kblk == 5u ? ysz >> 2 : 0) + (size_t)(8u * my_) * stride + 8u * mx;
+  }
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    int y[8];
+    idct8(ws[r][0], ws[r][1], ws[r][2], ws[r][3], ws[r][4], ws[r][5], ws[r][6], ws[r][7], y);
+    uint2 o;
+    o.x = px(y[0]) | (px(y[1]) << 8) | (px(y[2]) << 16) | (px(y[3]) << 24);
+    o.y = px(y[4]) | (px(y[5]) << 8) | (px(y[6]) << 16) | (px(y[7]) << 24);
+    *(uint2*)(dst + (size_t)r * stride) = o;
+  }
+}
+
+}  // namespace mirtj

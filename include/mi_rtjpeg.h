@@ -1,0 +1,119 @@
+/*
+ * mi_rtjpeg.h — C ABI of the MI355X (gfx950) RTjpeg frame-decode path.
+ *
+ * This is the drop-in boundary for gmerlin-avdecoder's in-tree RTjpeg decoder: plain C
+ * types, no HIP or torch types.  The library behind it (libmi_rtjpeg.so) holds only
+ * hand-written HIP kernels plus the host logic that launches them; there is no CPU decode
+ * path — every entry point fails (and says why through mi_rtj_last_error) when no gfx950
+ * device is usable.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the
+ * gmerlin-avdecoder tree).  INTEGRATION.md shows the replacement lib/video_rtjpeg.c that
+ * binds them into the bgav_video_decoder_t table.
+ */
+#ifndef MI_RTJPEG_H
+#define MI_RTJPEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_RTJ_HEADER_SIZE 12 /* RTJPEG_HEADER_SIZE, include/RTjpeg.h:142 */
+
+enum {
+  MI_RTJ_OK = 0,
+  MI_RTJ_ERR_NO_DEVICE = -1, /* no HIP device / not gfx950 */
+  MI_RTJ_ERR_HIP = -2,       /* a HIP runtime call failed (text in mi_rtj_last_error) */
+  MI_RTJ_ERR_ARG = -3,       /* NULL / out-of-range argument */
+  MI_RTJ_ERR_GEOMETRY = -4,  /* header width/height not positive multiples of 16: the reference's
+                                macroblock loop (lib/RTjpeg.c:2701-2703) never terminates on these */
+  MI_RTJ_ERR_NOMEM = -5
+};
+
+typedef struct mi_rtj_ctx mi_rtj_ctx;   /* one per decoder instance == one RTjpeg_t (include/RTjpeg.h:40-74) */
+typedef struct mi_rtj_plan mi_rtj_plan; /* a batch of packets laid out for the device */
+
+/* ---- device probe: what a .probe callback of bgav_video_decoder_t would ask
+ *      (include/avdec_private.h:95; precedent lib/video_v4l2_m2m.c:43-60) ---- */
+int mi_rtj_device_count(void); /* number of usable gfx950 devices, 0 when none */
+
+/* ---- instance lifecycle ---- */
+/* replaces RTjpeg_init (lib/RTjpeg.c:2495-2502) as called by init_rtjpeg (lib/video_rtjpeg.c:48).
+ * device < 0 picks the current device (LOCAL_RANK / HIP_VISIBLE_DEVICES decide).  NULL on failure. */
+mi_rtj_ctx *mi_rtj_create(int device);
+/* replaces RTjpeg_close (lib/RTjpeg.c:2504-2508) as called by close_rtjpeg (lib/video_rtjpeg.c:98). */
+void mi_rtj_destroy(mi_rtj_ctx *ctx);
+/* Text of the last failure on this instance (ctx == NULL: last mi_rtj_create failure). */
+const char *mi_rtj_last_error(const mi_rtj_ctx *ctx);
+
+/* ---- one packet in, one frame out ----
+ * replaces RTjpeg_decompress(rtj, p->buf.buf, priv->frame->planes) followed by
+ * gavl_video_frame_copy(format, f, priv->frame)  (lib/video_rtjpeg.c:81-83; lib/RTjpeg.c:3565-3586).
+ * The decoded picture persists on the device between calls exactly like priv->frame does, so
+ * 0xFF "unchanged" blocks (lib/RTjpeg.c:2704) keep the previous frame's pixels.
+ * dst[0..2]/dst_stride[0..2] describe the caller's Y, U, V planes (gavl_video_frame_t planes[]/
+ * strides[]); the crop_w x crop_h top-left region (image_width x image_height) is copied.
+ * dst == NULL decodes into the persistent frame only.  Returns MI_RTJ_OK or an error. */
+int mi_rtj_decode(mi_rtj_ctx *ctx, const uint8_t *pkt, size_t len, uint8_t *const dst[3],
+                  const int dst_stride[3], int crop_w, int crop_h);
+/* Geometry and effective quality the last mi_rtj_decode / plan used (RTjpeg_t width/height/Q). */
+void mi_rtj_get_state(const mi_rtj_ctx *ctx, int *width, int *height, int *quality);
+
+/* ---- device memory (HBM) owned by the instance; plain pointers ---- */
+void *mi_rtj_dev_alloc(mi_rtj_ctx *ctx, size_t bytes); /* padded so kernels may over-read 64 B */
+void mi_rtj_dev_free(mi_rtj_ctx *ctx, void *dptr);
+int mi_rtj_h2d(mi_rtj_ctx *ctx, void *dptr, const void *src, size_t bytes);
+int mi_rtj_d2h(mi_rtj_ctx *ctx, void *dst, const void *dptr, size_t bytes);
+int mi_rtj_dev_memset(mi_rtj_ctx *ctx, void *dptr, int value, size_t bytes);
+int mi_rtj_sync(mi_rtj_ctx *ctx); /* wait for everything queued on the instance's stream */
+
+/* ---- batches of packets (independent frames or streams), device resident ----
+ * A plan applies RTjpeg_decompress's header logic (size / quality change, lib/RTjpeg.c:3568-3579)
+ * to n packets in order, starting from the instance's current state, and fixes where each
+ * packet lives in a device stream buffer and where its planes go in a device output buffer
+ * (Y at out_offset, then U, then V, contiguous, stride = width as lib/RTjpeg.c:2708,2741 write).
+ * headers: n * 12 bytes (host).  pkt_offset/pkt_len: whole packets, header included. */
+mi_rtj_plan *mi_rtj_plan_create(mi_rtj_ctx *ctx, int n, const uint8_t *headers,
+                                const uint64_t *pkt_offset, const uint32_t *pkt_len,
+                                const uint64_t *out_offset);
+void mi_rtj_plan_destroy(mi_rtj_plan *plan);
+/* Queue the whole hot path for the batch on the instance's stream: block-offset index
+ * (RTjpeg_s2b's length semantics, lib/RTjpeg.c:157-186) then dequant + IDCT + plane scatter
+ * (lib/RTjpeg.c:2209-2332, 2688-2749).  Asynchronous; pair with mi_rtj_sync. */
+int mi_rtj_plan_decode(mi_rtj_plan *plan, const void *d_stream, void *d_out);
+/* Frames in the plan, total blocks, total algorithmic bytes (packet bytes read + plane bytes written). */
+void mi_rtj_plan_info(const mi_rtj_plan *plan, int *n_frames, uint64_t *n_blocks,
+                      uint64_t *bytes_in, uint64_t *bytes_out);
+/* Per-kernel device time: when enabled, mi_rtj_plan_decode brackets each kernel with HIP events
+ * on the launch stream.  mi_rtj_plan_times sums them since the last reset (after a sync):
+ * ms[0] = index kernel(s), ms[1] = decode kernel, launches = number of mi_rtj_plan_decode calls. */
+void mi_rtj_plan_profile(mi_rtj_plan *plan, int enable);
+int mi_rtj_plan_times(mi_rtj_plan *plan, float ms[2], int *launches);
+/* Test hook: copy the plan's block-start index (relative to each packet's first data byte,
+ * nblocks+1 entries per frame, frames back to back) to the host after a decode. */
+int mi_rtj_plan_read_index(mi_rtj_plan *plan, uint32_t *dst, size_t max_entries);
+
+/* ---- stream generator (RTjpeg_compress, lib/RTjpeg.c:3488-3524, intra only) ----
+ * Synthetic frames (gradient + hashed noise, the tests hold a numpy twin):
+ * n frames numbered first_frame.., each 1.5*w*h bytes, back to back in d_frames. */
+int mi_rtj_synth_frames(mi_rtj_ctx *ctx, int w, int h, int first_frame, int n, uint32_t seed,
+                        int amp, void *d_frames);
+/* Encode n frames (w x h, contiguous planes) at quality Q into d_stream, packets back to back
+ * (each start aligned to `align` bytes, a power of two >= 1).  Host arrays pkt_offset/pkt_len
+ * (n entries) receive the layout.  d_stream must hold mi_rtj_encode_bound(w,h,n,align) bytes. */
+size_t mi_rtj_encode_bound(int w, int h, int n, int align);
+int mi_rtj_encode_frames(mi_rtj_ctx *ctx, int w, int h, int Q, int n, const void *d_frames,
+                         void *d_stream, int align, uint64_t *pkt_offset, uint32_t *pkt_len);
+
+/* Dequantiser tables the device uses for quality Q (1..255): 64 luma + 64 chroma entries in
+ * natural order and the lb8/cb8 counts — the values RTjpeg_get_tables returns
+ * (lib/RTjpeg.c:2371-2378) after RTjpeg_set_quality. */
+int mi_rtj_get_tables(int Q, int32_t tables[128], int *lb8, int *cb8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,314 @@
+"""Parity tests proper: the HIP path, called through the C ABI (libmi_rtjpeg.so), against the CPU
+oracle and the committed golden vectors.  Bit-exact everywhere — this is integer/byte work.
+Run on the GPU box with `pytest -m gpu`."""
+import numpy as np
+import pytest
+
+import rtjlib as R
+from pkg import P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    d = P.MiRtj()
+    yield d
+    d.close()
+
+
+@pytest.fixture(scope="module")
+def G():
+    return np.load(R.GOLDEN + "/rtjpeg_golden.npz")
+
+
+def frame_bytes(w, h):
+    return w * h * 3 // 2
+
+
+def first_diff(a, b):
+    d = np.nonzero(a != b)[0]
+    return None if d.size == 0 else (int(d[0]), int(a[d[0]]), int(b[d[0]]), int(d.size))
+
+
+def batch_decode(dev, pkts, prefill=None, align=1, check_index=True):
+    """Independent decode of each packet through a plan.  Returns list of plane arrays."""
+    d_stream, po, pl, hdrs = dev.upload_packets(pkts, align=align)
+    sizes = [frame_bytes(int(p[6]) | (int(p[7]) << 8), int(p[8]) | (int(p[9]) << 8)) for p in pkts]
+    oo = np.zeros(len(pkts), np.uint64)
+    cur = 0
+    for i, s in enumerate(sizes):
+        oo[i] = cur
+        cur += (s + 255) // 256 * 256
+    d_out = dev.alloc(cur)
+    dev.memset(d_out, 0 if prefill is None else prefill, cur)
+    plan = dev.plan(hdrs, po, pl, oo)
+    plan.decode(d_stream, d_out)
+    dev.sync()
+    outs = [dev.d2h(d_out, sizes[i], offset=int(oo[i])) for i in range(len(pkts))]
+    if check_index:
+        idx = plan.read_index()
+        k = 0
+        dec = R.OracleDecoder()
+        for i, p in enumerate(pkts):
+            want = dec.block_offsets(p).astype(np.int64) - 12
+            got = idx[k:k + want.size].astype(np.int64)
+            k += want.size
+            bad = np.nonzero(got != want)[0]
+            assert bad.size == 0, f"block index of packet {i}: first mismatch at block {bad[0]}: got {got[bad[0]]} want {want[bad[0]]} ({bad.size} wrong of {want.size})"
+    plan.close()
+    dev.free(d_stream)
+    dev.free(d_out)
+    return outs
+
+
+# --------------------------------------------------------------------------- golden vectors
+def test_golden_intra_streams_batch(dev, G):
+    pkts = [G[f"intra{ci}_{n}_pkt"] for (ci, n, *_) in G["intra_meta"]]
+    outs = batch_decode(dev, pkts, align=1)
+    for (ci, n, *_), got in zip(G["intra_meta"], outs):
+        assert first_diff(got, G[f"intra{ci}_{n}_planes"]) is None, (ci, n)
+
+
+def test_golden_adversarial_known_answers(dev, G):
+    pkts = [G[f"kat_{ki}_pkt"] for (ki, *_) in G["kat_meta"]]
+    outs = batch_decode(dev, pkts, prefill=99)
+    for (ki, *_), got in zip(G["kat_meta"], outs):
+        assert first_diff(got, G[f"kat_{ki}_planes"]) is None, ki
+
+
+def test_golden_inter_sequence_single_stream(dev, G):
+    """0xFF blocks keep the previous picture: the one-packet path holds it on the device like
+    priv->frame (lib/video_rtjpeg.c:31-35)."""
+    w, h, Q, key, lm, cm, nfr = [int(x) for x in G["inter_meta"]]
+    d = P.MiRtj()
+    out = np.zeros(frame_bytes(w, h), np.uint8)
+    for n in range(nfr):
+        d.decode(G[f"inter_{n}_pkt"], out)
+        assert first_diff(out, G[f"inter_{n}_planes"]) is None, n
+    assert d.state() == (w, h, Q)
+    d.close()
+
+
+# --------------------------------------------------------------------------- oracle, seeded
+@pytest.mark.parametrize("w,h,Q,amp,n", [(16, 16, 255, 8, 3), (64, 48, 200, 30, 4), (320, 240, 255, 8, 6),
+                                          (320, 240, 128, 64, 3), (336, 256, 1, 64, 2), (1920, 1088, 255, 8, 2),
+                                          (1920, 1088, 64, 64, 1), (4096, 16, 90, 20, 2), (16, 2048, 255, 64, 2)])
+def test_decode_matches_oracle(dev, w, h, Q, amp, n):
+    enc = R.OracleEncoder(w, h, Q)
+    pkts = [enc.encode(R.synth_frame(w, h, i, seed=11, amp=amp)) for i in range(n)]
+    outs = batch_decode(dev, pkts, align=1)  # align=1: packets start at arbitrary byte addresses
+    dec = R.OracleDecoder()
+    for i, (p, got) in enumerate(zip(pkts, outs)):
+        want = np.zeros(frame_bytes(w, h), np.uint8)
+        dec.decode(p, want)
+        assert first_diff(got, want) is None, (i, first_diff(got, want))
+
+
+def test_mixed_batch_sizes_and_qualities(dev):
+    """cfg 5 shape: one plan holding packets of different geometry and quality."""
+    rng = np.random.default_rng(5)
+    pkts = []
+    for i in range(24):
+        w, h = [(320, 240), (64, 48), (640, 368), (176, 144)][i % 4]
+        Q = int(rng.choice([64, 128, 255, 30]))
+        pkts.append(R.OracleEncoder(w, h, Q).encode(R.synth_frame(w, h, i, seed=i, amp=int(rng.integers(0, 60)))))
+    outs = batch_decode(dev, pkts, align=1)
+    dec = R.OracleDecoder()  # the plan applies the header state machine in order, like one decoder
+    for i, (p, got) in enumerate(zip(pkts, outs)):
+        w, h = int(p[6]) | (int(p[7]) << 8), int(p[8]) | (int(p[9]) << 8)
+        want = np.zeros(frame_bytes(w, h), np.uint8)
+        dec.decode(p, want)
+        assert first_diff(got, want) is None, i
+
+
+def test_skip_blocks_leave_destination_untouched_in_batches(dev):
+    w, h, Q = 320, 240, 200
+    enc = R.OracleEncoder(w, h, Q, key_rate=6, lmask=3, cmask=3)
+    pkts = [enc.encode(R.synth_frame(w, h, n // 4, seed=9, amp=2)) for n in range(8)]
+    assert any((p[12:] == 255).any() for p in pkts)
+    outs = batch_decode(dev, pkts, prefill=0x5A)
+    for p, got in zip(pkts, outs):
+        want = np.full(frame_bytes(w, h), 0x5A, np.uint8)
+        R.OracleDecoder().decode(p, want)
+        assert first_diff(got, want) is None
+
+
+def test_random_token_streams(dev):
+    """Adversarial blocks (random bytes, random runs, some 0xFF) at qualities where the int16
+    narrowing of RTjpeg_s2b and DESCALE is observable."""
+    from golden.make_golden import adversarial_packet
+    rng = np.random.default_rng(2025)
+    pkts, qs = [], []
+    for Q in (1, 2, 3, 8, 31, 129, 192, 255):
+        _, _, lb8, cb8, _, _ = R.oracle_tables(Q)
+        for (w, h) in ((48, 32), (160, 16)):
+            pkts.append(adversarial_packet(rng, w, h, Q, lb8, cb8, skip_prob=0.1))
+            qs.append(Q)
+    # each packet gets its own decoder state in the oracle; do the same on the device
+    for p, Q in zip(pkts, qs):
+        w, h = int(p[6]) | (int(p[7]) << 8), int(p[8]) | (int(p[9]) << 8)
+        d = P.MiRtj()
+        got = np.full(frame_bytes(w, h), 7, np.uint8)
+        want = got.copy()
+        # pre-seed the device picture so that skipped blocks are comparable
+        d.decode(R.OracleEncoder(w, h, 100).encode(R.synth_frame(w, h, 0)), got)
+        od = R.OracleDecoder()
+        od.decode(R.OracleEncoder(w, h, 100).encode(R.synth_frame(w, h, 0)), want)
+        d.decode(p, got)
+        od.decode(p, want)
+        assert first_diff(got, want) is None, Q
+        d.close()
+
+
+def test_truncated_and_empty_packets(dev):
+    w, h = 64, 32
+    pkt = R.OracleEncoder(w, h, 255).encode(R.synth_frame(w, h, 0, amp=30))
+    cases = [pkt[:12], pkt[:13], pkt[: 12 + 40], pkt[: pkt.size // 2], pkt[:-1]]
+    outs = batch_decode(dev, cases)
+    for c, got in zip(cases, outs):
+        want = np.zeros(frame_bytes(w, h), np.uint8)
+        R.OracleDecoder().decode(c, want)
+        assert first_diff(got, want) is None, c.size
+
+
+def test_quality_zero_state_machine(dev):
+    w, h = 32, 16
+    enc = R.OracleEncoder(w, h, 100)
+    p0 = enc.encode(R.synth_frame(w, h, 0))
+    p0[10] = 0
+    p1 = enc.encode(R.synth_frame(w, h, 1))
+    d, od = P.MiRtj(), R.OracleDecoder()
+    got = np.zeros(frame_bytes(w, h), np.uint8)
+    want = got.copy()
+    for p in (p0, p1, p0):
+        d.decode(p, got)
+        od.decode(p, want)
+        assert first_diff(got, want) is None
+        assert d.state()[2] == od.quality()
+    d.close()
+
+
+def test_bad_geometry_and_arguments(dev):
+    pkt = np.zeros(64, np.uint8)
+    pkt[4], pkt[6], pkt[8], pkt[10] = 12, 24, 16, 100
+    with pytest.raises(P.MiRtjError, match="multiples of 16"):
+        dev.decode(pkt, np.zeros(24 * 16 * 3 // 2, np.uint8))
+    with pytest.raises(P.MiRtjError, match="header"):
+        dev.decode(pkt[:5], None)
+
+
+def test_crop_and_strides_like_gavl_frame_copy(dev):
+    """1080p is coded as 1920x1088 and handed back as the 1920x1080 crop with the caller's strides
+    (lib/video_rtjpeg.c:50-51,82)."""
+    w, h, cw, ch = 1920, 1088, 1920, 1080
+    pkt = R.OracleEncoder(w, h, 255).encode(R.synth_frame(w, h, 3))
+    want_full = np.zeros(frame_bytes(w, h), np.uint8)
+    R.OracleDecoder().decode(pkt, want_full)
+    strides = (2048, 1024, 1024)
+    out = np.full(strides[0] * ch + 2 * strides[1] * (ch // 2), 0xEE, np.uint8)
+    d = P.MiRtj()
+    d.decode(pkt, out, crop=(cw, ch), strides=strides)
+    y = out[: strides[0] * ch].reshape(ch, strides[0])
+    u = out[strides[0] * ch: strides[0] * ch + strides[1] * (ch // 2)].reshape(ch // 2, strides[1])
+    v = out[strides[0] * ch + strides[1] * (ch // 2):].reshape(ch // 2, strides[1])
+    wy = want_full[: w * h].reshape(h, w)
+    wu = want_full[w * h: w * h * 5 // 4].reshape(h // 2, w // 2)
+    wv = want_full[w * h * 5 // 4:].reshape(h // 2, w // 2)
+    assert np.array_equal(y[:, :cw], wy[:ch, :cw]) and (y[:, cw:] == 0xEE).all()
+    assert np.array_equal(u[:, : cw // 2], wu[: ch // 2, : cw // 2]) and (u[:, cw // 2:] == 0xEE).all()
+    assert np.array_equal(v[:, : cw // 2], wv[: ch // 2, : cw // 2])
+    d.close()
+
+
+# --------------------------------------------------------------------------- generator side (N1)
+@pytest.mark.parametrize("w,h,amp", [(64, 48, 8), (320, 240, 64), (1920, 1088, 8)])
+def test_synth_matches_numpy_twin(dev, w, h, amp):
+    n = 3
+    d = dev.synth(w, h, 5, n, seed=777, amp=amp)
+    dev.sync()
+    got = dev.d2h(d, frame_bytes(w, h) * n)
+    dev.free(d)
+    for i in range(n):
+        want = R.synth_frame(w, h, 5 + i, seed=777, amp=amp)
+        assert first_diff(got[i * want.size:(i + 1) * want.size], want) is None, i
+
+
+@pytest.mark.parametrize("w,h,Q,amp", [(64, 48, 255, 8), (320, 240, 128, 64), (320, 240, 1, 64), (1920, 1088, 255, 8)])
+def test_encoder_matches_oracle_bytes(dev, w, h, Q, amp):
+    n = 3
+    d_fr = dev.synth(w, h, 0, n, seed=31, amp=amp)
+    d_st, po, pl = dev.encode(w, h, Q, n, d_fr, align=1)
+    dev.sync()
+    for i in range(n):
+        got = dev.d2h(d_st, int(pl[i]), offset=int(po[i]))
+        want = R.OracleEncoder(w, h, Q).encode(R.synth_frame(w, h, i, seed=31, amp=amp))
+        assert got.size == want.size and first_diff(got, want) is None, i
+    dev.free(d_fr)
+    dev.free(d_st)
+
+
+# --------------------------------------------------------------------------- benchmark sizes
+@pytest.mark.parametrize("row", [0, 1, 2, 3])
+def test_benchmark_size_digests_from_reference(dev, G, row):
+    """Content, packet and planes regenerated entirely on the device must hash to what the
+    reference's own encoder/decoder produced for the same seeded frame (tests/golden)."""
+    w, h, Q, amp, n, plen = [int(x) for x in G["big_meta"][row]]
+    dfr, dpkt, dpl = [str(x) for x in G["big_digests"][row]]
+    d_fr = dev.synth(w, h, n, 1, seed=12345, amp=amp)
+    d_st, po, pl = dev.encode(w, h, Q, 1, d_fr)
+    dev.sync()
+    assert R.digest(dev.d2h(d_fr, frame_bytes(w, h))) == dfr
+    assert int(pl[0]) == plen
+    pkt = dev.d2h(d_st, plen, offset=int(po[0]))
+    assert R.digest(pkt) == dpkt
+    d_out = dev.alloc(frame_bytes(w, h))
+    plan = dev.plan(pkt[:12], po, pl, np.zeros(1, np.uint64))
+    plan.decode(d_st, d_out)
+    dev.sync()
+    assert R.digest(dev.d2h(d_out, frame_bytes(w, h))) == dpl
+    for p in (d_fr, d_st, d_out):
+        dev.free(p)
+
+
+def test_full_size_batch_properties(dev):
+    """256 distinct 1080p frames (BASELINE config): decode is deterministic (two passes give the
+    same bytes), independent of batch position (frame k decoded alone == inside the batch), and
+    a sample of frames matches the oracle."""
+    w, h, Q, n = 1920, 1088, 255, 256
+    fsz = frame_bytes(w, h)
+    d_fr = dev.synth(w, h, 0, n, seed=12345, amp=8)
+    d_st, po, pl = dev.encode(w, h, Q, n, d_fr)
+    dev.free(d_fr)
+    hdr = dev.d2h(d_st, 12, offset=int(po[0]))
+    hdrs = np.tile(hdr, (n, 1))
+    for i in range(n):  # only framesize differs between headers
+        hdrs[i, 0:4] = np.frombuffer(np.uint32(pl[i]).tobytes(), np.uint8)
+    oo = np.arange(n, dtype=np.uint64) * np.uint64(fsz)
+    d_out = dev.alloc(fsz * n)
+    plan = dev.plan(hdrs, po, pl, oo)
+    plan.decode(d_st, d_out)
+    dev.sync()
+    sample = [0, 1, 127, 255]
+    first = {k: dev.d2h(d_out, fsz, offset=k * fsz) for k in sample}
+    sums1 = [int(dev.d2h(d_out, 4096, offset=k * fsz + 12345).sum()) for k in range(n)]
+    dev.memset(d_out, 0, fsz * n)
+    plan.decode(d_st, d_out)
+    dev.sync()
+    for k in sample:
+        again = dev.d2h(d_out, fsz, offset=k * fsz)
+        assert first_diff(again, first[k]) is None
+        pkt = dev.d2h(d_st, int(pl[k]), offset=int(po[k]))
+        want = np.zeros(fsz, np.uint8)
+        R.OracleDecoder().decode(pkt, want)
+        assert first_diff(again, want) is None, k
+        alone = np.zeros(fsz, np.uint8)
+        dd = P.MiRtj()
+        dd.decode(pkt, alone)
+        dd.close()
+        assert first_diff(alone, want) is None, k
+    sums2 = [int(dev.d2h(d_out, 4096, offset=k * fsz + 12345).sum()) for k in range(n)]
+    assert sums1 == sums2
+    plan.close()
+    dev.free(d_st)
+    dev.free(d_out)
