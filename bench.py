@@ -142,7 +142,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    ms_index, ms_decode, launches = plan.times()
+    ktimes, launches = plan.times()
     plan.profile(False)
 
     tot_frames = n * world
@@ -156,17 +156,18 @@ def main():
 
     if rank == 0:
         fps = tot_frames * a.steps / dt
-        # per-launch figures of the two kernels of the path (this rank)
-        k_idx = ms_index / max(launches, 1)
-        k_dec = ms_decode / max(launches, 1)
+        # per-launch figures of every kernel of the path (this rank), from HIP events on the launch stream
         alg_bytes = info["bytes_in"] + info["bytes_out"]  # packet read once + planes written once
-        kernels = {
-            "k_index_walk": {"ms": round(k_idx, 4), "alg_bytes": info["bytes_in"],
-                             "gbs": round(info["bytes_in"] / (k_idx * 1e-3) / 1e9, 2) if k_idx > 0 else None},
-            "k_decode": {"ms": round(k_dec, 4), "alg_bytes": alg_bytes,
-                         "gbs": round(alg_bytes / (k_dec * 1e-3) / 1e9, 2) if k_dec > 0 else None},
-        }
-        dom = "k_index_walk" if k_idx > k_dec else "k_decode"
+        alg = {"k_index_summarize": info["bytes_in"], "k_index_resolve": 0, "k_index_emit": info["bytes_in"],
+               "k_decode": alg_bytes}
+        kernels = {}
+        for name, ms in ktimes.items():
+            per = ms / max(launches, 1)
+            if per <= 0:
+                continue
+            kernels[name] = {"ms": round(per, 4), "alg_bytes": alg[name],
+                             "gbs": round(alg[name] / (per * 1e-3) / 1e9, 2)}
+        dom = max(kernels, key=lambda k: kernels[k]["ms"])
         ach = kernels[dom]["gbs"] or 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -189,6 +190,7 @@ def main():
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "alg_bytes_per_launch": kernels[dom]["alg_bytes"], "ms_per_launch": kernels[dom]["ms"]},
             "kernels": kernels,
+            "index_mode": os.environ.get("MI_RTJ_INDEX", "parallel"),
             "path_gbs": round(alg_bytes * a.steps / dt / 1e9, 2),
         }
         if world == 1 and not a.no_cpu:

@@ -29,6 +29,9 @@ EXPORTS = ["mi_rtj_device_count", "mi_rtj_create", "mi_rtj_destroy", "mi_rtj_las
            "mi_rtj_get_tables"]
 
 
+KERNELS = ("k_index_summarize", "k_index_resolve", "k_index_emit", "k_decode")
+
+
 def load():
     global _LIB
     if _LIB is not None:
@@ -109,10 +112,10 @@ class Plan:
         self.owner.L.mi_rtj_plan_profile(self.h, 1 if on else 0)
 
     def times(self):
-        ms = (C.c_float * 2)()
+        ms = (C.c_float * 4)()
         n = C.c_int()
         self.owner._chk(self.owner.L.mi_rtj_plan_times(self.h, ms, C.byref(n)))
-        return float(ms[0]), float(ms[1]), n.value
+        return dict(zip(KERNELS, [float(x) for x in ms])), n.value
 
     def read_index(self):
         cnt = self.info()["blocks"] + self.n

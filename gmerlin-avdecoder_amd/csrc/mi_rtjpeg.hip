@@ -15,6 +15,7 @@
 #include "rtj_common.h"
 #include "rtj_decode_kernels.h"
 #include "rtj_encode_kernels.h"
+#include "rtj_index_kernels.h"
 #include "rtj_tables.h"
 
 using namespace mirtj;
@@ -53,10 +54,15 @@ struct mi_rtj_plan {
   std::vector<FrameDev> h_frames;
   FrameDev* d_frames = nullptr;
   uint32_t* d_blkoff = nullptr;
+  uint32_t* d_summary = nullptr;    // [total chunks][kEntries]
+  uint32_t* d_chunk_pos = nullptr;  // [total chunks + n]
+  uint32_t* d_chunk_mb = nullptr;
   uint64_t n_blocks = 0, n_index = 0, bytes_in = 0, bytes_out = 0;
-  uint32_t max_groups = 0;
+  uint64_t n_chunks = 0, n_chunk_entries = 0;
+  uint32_t max_groups = 0, max_chunks = 0;
   bool profile = false;
-  std::vector<Timed> ev_index, ev_decode;  // one pair per launch while profiling
+  bool serial_index = false;        // MI_RTJ_INDEX=serial: one wave per packet (A/B baseline)
+  std::vector<Timed> ev[MI_RTJ_NUM_KERNELS];  // one pair per launch while profiling
   int launches = 0;
 };
 
@@ -120,6 +126,43 @@ int fill_frame(mi_rtj_ctx* c, const uint8_t* hdr, uint64_t pkt_off, uint32_t pkt
   f->blk_base = blk_base;
   f->mbw = (uint32_t)w / 16;
   f->nmb = f->mbw * ((uint32_t)h / 16);
+  f->nchunks = (f->data_len + kChunk - 1) / kChunk;
+  if (f->nchunks == 0) f->nchunks = 1;
+  return MI_RTJ_OK;
+}
+
+// per-chunk scratch of a plan (re)sized for its frames; chunk_base / sum_base are set here
+int plan_alloc_chunks(mi_rtj_plan* p) {
+  mi_rtj_ctx* c = p->ctx;
+  uint64_t chunks = 0, entries = 0;
+  p->max_chunks = 0;
+  for (auto& f : p->h_frames) {
+    f.sum_base = (uint32_t)chunks;
+    f.chunk_base = (uint32_t)entries;
+    chunks += f.nchunks;
+    entries += f.nchunks + 1;
+    if (f.nchunks > p->max_chunks) p->max_chunks = f.nchunks;
+  }
+  if (chunks > p->n_chunks) {
+    if (p->d_summary) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      (void)hipFree(p->d_summary);
+      p->d_summary = nullptr;
+    }
+    HIPCHK(c, hipMalloc((void**)&p->d_summary, sizeof(uint32_t) * kEntries * chunks));
+    p->n_chunks = chunks;
+  }
+  if (entries > p->n_chunk_entries) {
+    if (p->d_chunk_pos) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      (void)hipFree(p->d_chunk_pos);
+      (void)hipFree(p->d_chunk_mb);
+      p->d_chunk_pos = p->d_chunk_mb = nullptr;
+    }
+    HIPCHK(c, hipMalloc((void**)&p->d_chunk_pos, sizeof(uint32_t) * entries));
+    HIPCHK(c, hipMalloc((void**)&p->d_chunk_mb, sizeof(uint32_t) * entries));
+    p->n_chunk_entries = entries;
+  }
   return MI_RTJ_OK;
 }
 
@@ -133,27 +176,44 @@ int plan_upload(mi_rtj_plan* p) {
 
 int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
   mi_rtj_ctx* c = p->ctx;
-  Timed ti, td;
-  if (p->profile) {
-    HIPCHK(c, hipEventCreate(&ti.a));
-    HIPCHK(c, hipEventCreate(&ti.b));
-    HIPCHK(c, hipEventCreate(&td.a));
-    HIPCHK(c, hipEventCreate(&td.b));
-    HIPCHK(c, hipEventRecord(ti.a, c->stream));
+  const uint8_t* st = (const uint8_t*)d_stream;
+  Timed t[MI_RTJ_NUM_KERNELS];
+  auto begin = [&](int k) -> int {
+    if (!p->profile) return MI_RTJ_OK;
+    HIPCHK(c, hipEventCreate(&t[k].a));
+    HIPCHK(c, hipEventCreate(&t[k].b));
+    HIPCHK(c, hipEventRecord(t[k].a, c->stream));
+    return MI_RTJ_OK;
+  };
+  auto end = [&](int k) -> int {
+    if (!p->profile) return MI_RTJ_OK;
+    HIPCHK(c, hipEventRecord(t[k].b, c->stream));
+    p->ev[k].push_back(t[k]);
+    return MI_RTJ_OK;
+  };
+  int rc;
+  if (p->serial_index) {
+    if ((rc = begin(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
+    hipLaunchKernelGGL(k_index_walk, dim3(p->n), dim3(64), 0, c->stream, p->d_frames, st, c->d_lut, p->d_blkoff);
+    if ((rc = end(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
+  } else {
+    if ((rc = begin(MI_RTJ_K_SUMMARIZE)) != MI_RTJ_OK) return rc;
+    hipLaunchKernelGGL(k_index_summarize, dim3(p->max_chunks, p->n), dim3(kSumThreads), 0, c->stream, p->d_frames, st,
+                       c->d_lut, p->d_summary);
+    if ((rc = end(MI_RTJ_K_SUMMARIZE)) != MI_RTJ_OK) return rc;
+    if ((rc = begin(MI_RTJ_K_RESOLVE)) != MI_RTJ_OK) return rc;
+    hipLaunchKernelGGL(k_index_resolve, dim3(p->n), dim3(256), 0, c->stream, p->d_frames, p->d_summary,
+                       p->d_chunk_pos, p->d_chunk_mb);
+    if ((rc = end(MI_RTJ_K_RESOLVE)) != MI_RTJ_OK) return rc;
+    if ((rc = begin(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
+    hipLaunchKernelGGL(k_index_emit, dim3(p->max_chunks, p->n), dim3(64), 0, c->stream, p->d_frames, st, c->d_lut,
+                       p->d_chunk_pos, p->d_chunk_mb, p->d_blkoff);
+    if ((rc = end(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
   }
-  hipLaunchKernelGGL(k_index_walk, dim3(p->n), dim3(64), 0, c->stream, p->d_frames, (const uint8_t*)d_stream,
-                     c->d_lut, p->d_blkoff);
-  if (p->profile) {
-    HIPCHK(c, hipEventRecord(ti.b, c->stream));
-    HIPCHK(c, hipEventRecord(td.a, c->stream));
-  }
-  hipLaunchKernelGGL(k_decode, dim3(p->max_groups, p->n), dim3(kDecThreads), 0, c->stream, p->d_frames,
-                     (const uint8_t*)d_stream, c->d_lut, p->d_blkoff, (uint8_t*)d_out);
-  if (p->profile) {
-    HIPCHK(c, hipEventRecord(td.b, c->stream));
-    p->ev_index.push_back(ti);
-    p->ev_decode.push_back(td);
-  }
+  if ((rc = begin(MI_RTJ_K_DECODE)) != MI_RTJ_OK) return rc;
+  hipLaunchKernelGGL(k_decode, dim3(p->max_groups, p->n), dim3(kDecThreads), 0, c->stream, p->d_frames, st, c->d_lut,
+                     p->d_blkoff, (uint8_t*)d_out);
+  if ((rc = end(MI_RTJ_K_DECODE)) != MI_RTJ_OK) return rc;
   HIPCHK(c, hipGetLastError());
   p->launches++;
   return MI_RTJ_OK;
@@ -326,10 +386,18 @@ mi_rtj_plan* mi_rtj_plan_create(mi_rtj_ctx* c, int n, const uint8_t* headers, co
     if (groups > p->max_groups) p->max_groups = groups;
   }
   p->n_index = blk_base;
-  if (hipSetDevice(c->device) != hipSuccess ||
-      hipMalloc((void**)&p->d_blkoff, sizeof(uint32_t) * p->n_index) != hipSuccess) {
+  {
+    const char* mode = getenv("MI_RTJ_INDEX");
+    p->serial_index = mode && strcmp(mode, "serial") == 0;
+  }
+  if (hipSetDevice(c->device) != hipSuccess || plan_alloc_chunks(p) != MI_RTJ_OK) {
+    mi_rtj_plan_destroy(p);
+    return nullptr;
+  }
+  if (
+hipMalloc((void**)&p->d_blkoff, sizeof(uint32_t) * p->n_index) != hipSuccess) {
     fail(c, MI_RTJ_ERR_NOMEM, "hipMalloc(block index, %llu entries) failed", (unsigned long long)p->n_index);
-    delete p;
+    mi_rtj_plan_destroy(p);
     return nullptr;
   }
   if (plan_upload(p) != MI_RTJ_OK) {
@@ -343,10 +411,12 @@ void mi_rtj_plan_destroy(mi_rtj_plan* p) {
   if (!p) return;
   (void)hipSetDevice(p->ctx->device);
   (void)hipStreamSynchronize(p->ctx->stream);
-  drop_events(p->ev_index);
-  drop_events(p->ev_decode);
+  for (auto& v : p->ev) drop_events(v);
   if (p->d_frames) (void)hipFree(p->d_frames);
   if (p->d_blkoff) (void)hipFree(p->d_blkoff);
+  if (p->d_summary) (void)hipFree(p->d_summary);
+  if (p->d_chunk_pos) (void)hipFree(p->d_chunk_pos);
+  if (p->d_chunk_mb) (void)hipFree(p->d_chunk_mb);
   delete p;
 }
 
@@ -367,28 +437,24 @@ void mi_rtj_plan_info(const mi_rtj_plan* p, int* n, uint64_t* nb, uint64_t* bi, 
 void mi_rtj_plan_profile(mi_rtj_plan* p, int enable) {
   if (!p) return;
   (void)hipStreamSynchronize(p->ctx->stream);
-  drop_events(p->ev_index);
-  drop_events(p->ev_decode);
+  for (auto& v : p->ev) drop_events(v);
   p->profile = enable != 0;
   p->launches = 0;
 }
 
-int mi_rtj_plan_times(mi_rtj_plan* p, float ms[2], int* launches) {
+int mi_rtj_plan_times(mi_rtj_plan* p, float ms[MI_RTJ_NUM_KERNELS], int* launches) {
   if (!p || !ms) return MI_RTJ_ERR_ARG;
   mi_rtj_ctx* c = p->ctx;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  ms[0] = ms[1] = 0.f;
-  for (auto& t : p->ev_index) {
-    float x = 0;
-    HIPCHK(c, hipEventElapsedTime(&x, t.a, t.b));
-    ms[0] += x;
+  for (int k = 0; k < MI_RTJ_NUM_KERNELS; k++) {
+    ms[k] = 0.f;
+    for (auto& t : p->ev[k]) {
+      float x = 0;
+      HIPCHK(c, hipEventElapsedTime(&x, t.a, t.b));
+      ms[k] += x;
+    }
   }
-  for (auto& t : p->ev_decode) {
-    float x = 0;
-    HIPCHK(c, hipEventElapsedTime(&x, t.a, t.b));
-    ms[1] += x;
-  }
-  if (launches) *launches = (int)p->ev_index.size();
+  if (launches) *launches = (int)p->ev[MI_RTJ_K_DECODE].size();
   return MI_RTJ_OK;
 }
 
@@ -458,6 +524,12 @@ int mi_rtj_decode(mi_rtj_ctx* c, const uint8_t* pkt, size_t len, uint8_t* const 
   }
   p->n_blocks = (uint64_t)f.nmb * 6;
   p->max_groups = (f.nmb + kMbPerGroup - 1) / kMbPerGroup;
+  {
+    const int rc2 = plan_alloc_chunks(p);
+    if (rc2 != MI_RTJ_OK) return rc2;
+    const char* mode = getenv("MI_RTJ_INDEX");
+    p->serial_index = mode && strcmp(mode, "serial") == 0;
+  }
   HIPCHK(c, hipMemcpyAsync(c->d_pkt, pkt, len, hipMemcpyHostToDevice, c->stream));
   int r = plan_upload(p);
   if (r != MI_RTJ_OK) return r;

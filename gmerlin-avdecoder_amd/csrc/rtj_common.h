@@ -31,9 +31,20 @@ struct FrameDev {
   uint32_t blk_base;  // first entry of this frame in the block-offset index (nblk+1 entries)
   uint32_t nmb;       // macroblocks = (w/16)*(h/16)
   uint32_t mbw;       // macroblocks per row
-  uint32_t pad;
+  uint32_t nchunks;   // stream chunks of kChunk bytes covering data_len (at least 1)
+  uint32_t chunk_base;  // first entry of this frame in the per-chunk arrays (nchunks+1 entries)
+  uint32_t sum_base;    // first chunk of this frame in the summary array (nchunks rows of kEntries)
+  uint32_t pad[2];
 };
-static_assert(sizeof(FrameDev) == 48, "FrameDev layout");
+static_assert(sizeof(FrameDev) == 64, "FrameDev layout");
+
+// Parallel block-offset index: the stream of a packet is cut into chunks of kChunk bytes.  A
+// macroblock is at most 6*64 bytes, so the first macroblock that starts inside a chunk starts at
+// one of kEntries offsets; a chunk's summary maps each of them to (exit offset, macroblock count).
+constexpr int kChunk = 3584;
+constexpr int kEntries = 384;
+constexpr int kTabN = kChunk + kEntries;  // positions that get block-length tables
+constexpr int kStageN = 4096;             // bytes staged per chunk (kTabN + 64 rounded up)
 
 constexpr int kMbPerGroup = 32;  // macroblocks per decode workgroup (3 waves: Ytop, Ybottom, chroma)
 

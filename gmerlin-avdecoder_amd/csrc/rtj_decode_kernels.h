@@ -49,42 +49,40 @@ __device__ __forceinline__ uint32_t token_weight(uint32_t b) {
 }
 
 // ---------------------------------------------------------------------------------------
-// k_index_walk: one wave per packet walks the block chain.
+// walk_blocks: one wave walks a stretch of the block chain of one packet.
 //
 // Lane i of the wave holds byte base+i of the stream (two 64-byte windows, "cur" and "nxt")
 // and the running sum W of token weights.  A block that starts at p with bt8 raw bytes ends at
 // the first byte e whose W reaches W[p+bt8] + (63-bt8): one compare + find-first-set per block.
 // The chain itself is serial (a block's length is only known once it has been read), so the
 // position lives in scalar registers and the vector unit is used 64 bytes at a time.
-// Output: byte offset of every block start relative to the first data byte, nblk+1 entries.
+// Walks blocks k0..k1-1 (k0 a multiple of 6) starting at byte p_start and writes out[k] = byte
+// offset of block k relative to the first data byte; with write_end also out[k1] = end position.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_index_walk(const FrameDev* __restrict__ frames,
-                                                    const uint8_t* __restrict__ stream,
-                                                    const QTab* __restrict__ lut,
-                                                    uint32_t* __restrict__ blkoff) {
-  const FrameDev f = frames[blockIdx.x];
-  const int lane = threadIdx.x;
+__device__ __forceinline__ void walk_blocks(const FrameDev& f, const uint8_t* __restrict__ stream,
+                                            const QTab* __restrict__ lut, uint32_t p_start, uint32_t k0,
+                                            uint32_t k1, bool write_end, uint32_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
   const uint8_t* g = stream + f.data_off;
   const uint32_t len = f.data_len;
-  const uint32_t nblk = f.nmb * 6u;
   const uint32_t lb8 = (uint32_t)lut[f.qidx].lb8, cb8 = (uint32_t)lut[f.qidx].cb8;
-  uint32_t* out = blkoff + f.blk_base;
 
   auto fetch = [&](uint32_t pos) -> uint32_t {
     const uint32_t i = pos + lane;
     return i < len ? (uint32_t)g[i] : 0u;
   };
 
-  uint32_t base = 0;
-  uint32_t cur = fetch(0), nxt = fetch(64), pf1 = fetch(128), pf2 = fetch(192), pf3 = fetch(256);
+  uint32_t base = p_start;
+  uint32_t cur = fetch(base), nxt = fetch(base + 64u), pf1 = fetch(base + 128u), pf2 = fetch(base + 192u),
+           pf3 = fetch(base + 256u);
   uint32_t Wc = wave_incl_scan(token_weight(cur));
   uint32_t Wn = wave_incl_scan(token_weight(nxt)) + (uint32_t)__builtin_amdgcn_readlane((int)Wc, 63);
 
-  uint32_t p = 0;       // current block start (uniform)
-  uint32_t ph = 0;      // block number within the macroblock, 0..5
-  uint32_t acc = 0;     // 64 offsets gathered one lane at a time, stored 256 B at once
+  uint32_t p = p_start;  // current block start (uniform)
+  uint32_t ph = 0;       // block number within the macroblock, 0..5
+  uint32_t acc = 0;      // up to 64 offsets gathered one lane at a time, stored 256 B at once
 
-  for (uint32_t k = 0;; ++k) {
+  for (uint32_t k = k0;; ++k) {
     while (p - base >= 64u) {  // slide the two windows forward
       base += 64u;
       cur = nxt;
@@ -95,9 +93,14 @@ __global__ __launch_bounds__(64) void k_index_walk(const FrameDev* __restrict__ 
       pf3 = fetch(base + 256u);
       Wn = wave_incl_scan(token_weight(nxt)) + (uint32_t)__builtin_amdgcn_readlane((int)Wc, 63);
     }
-    acc = (uint32_t)lane == (k & 63u) ? p : acc;
-    if ((k & 63u) == 63u) out[(k & ~63u) + lane] = acc;
-    if (k == nblk) break;
+    const bool last = k == k1;
+    if (!last || write_end) acc = (uint32_t)lane == (k & 63u) ? p : acc;
+    if ((k & 63u) == 63u || last) {
+      const uint32_t idx = (k & ~63u) + (uint32_t)lane;
+      const uint32_t top = last && !write_end ? k - 1u : k;  // k1 > k0 >= 0, so no wrap
+      if (idx >= k0 && idx <= top) out[idx] = acc;
+    }
+    if (last) break;
 
     const uint32_t lp = p - base;
     const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)lp);
@@ -126,7 +129,15 @@ __global__ __launch_bounds__(64) void k_index_walk(const FrameDev* __restrict__ 
     }
     p = base + e + 1u;
   }
-  if ((nblk & 63u) != 63u && (uint32_t)lane <= (nblk & 63u)) out[(nblk & ~63u) + lane] = acc;
+}
+
+// Whole packet by one wave: the simple (serial) index, kept as the A/B baseline of the parallel one.
+__global__ __launch_bounds__(64) void k_index_walk(const FrameDev* __restrict__ frames,
+                                                    const uint8_t* __restrict__ stream,
+                                                    const QTab* __restrict__ lut,
+                                                    uint32_t* __restrict__ blkoff) {
+  const FrameDev f = frames[blockIdx.x];
+  walk_blocks(f, stream, lut, 0u, 0u, f.nmb * 6u, true, blkoff + f.blk_base);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -1,0 +1,199 @@
+// rtj_index_kernels.h — parallel block-offset index for RTjpeg packets (gfx950).
+//
+// A block's length is only known after reading it (RTjpeg_s2b returns it, lib/RTjpeg.c:185), so
+// block n's offset depends on every block before it — 48,960 dependent steps per 1080p frame.
+// The index is therefore built in three launches that break the chain at fixed byte positions:
+//
+//   k_index_summarize  per chunk of kChunk stream bytes: length of a block of either type at
+//                      EVERY byte position (prefix sums of token weights + a bounded binary
+//                      search), composed into "next macroblock" jumps, then all kEntries possible
+//                      entry offsets are walked to the chunk's end -> (exit offset, MB count).
+//   k_index_resolve    per packet: chains the chunk summaries (one short serial walk in LDS) to
+//                      the true entry offset and first macroblock number of every chunk.
+//   k_index_emit       per chunk: one wave walks the true chain from the chunk's entry and
+//                      writes the byte offset of every block (rtj_decode_kernels.h walker).
+//
+// Block-length rule (lib/RTjpeg.c:157-186, 2704): first byte 0xFF -> 1 byte; otherwise 1 DC byte,
+// bt8 raw bytes, then tokens until 63-bt8 coefficient slots are covered, a token 64..127 covering
+// (token-63) slots and any other byte one slot.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rtj_common.h"
+#include "rtj_decode_kernels.h"
+
+namespace mirtj {
+
+constexpr int kSumThreads = 256;
+
+__global__ __launch_bounds__(kSumThreads) void k_index_summarize(const FrameDev* __restrict__ frames,
+                                                                  const uint8_t* __restrict__ stream,
+                                                                  const QTab* __restrict__ lut,
+                                                                  uint32_t* __restrict__ summary) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_b4[kStageN / 4];  // stream bytes
+  __shared__ __attribute__((aligned(16))) uint16_t s_w[kStageN];       // inclusive weight sums mod 2^16
+  __shared__ uint8_t s_nl[kTabN], s_nc[kTabN];                         // block length if luma / chroma
+  __shared__ uint16_t s_f[kChunk];                                     // macroblock length
+  __shared__ uint32_t s_wave[kSumThreads / 64];
+
+  const FrameDev f = frames[blockIdx.y];
+  const uint32_t c = blockIdx.x;
+  if (c >= f.nchunks) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint32_t cbase = c * (uint32_t)kChunk;
+  const uint8_t* s_b = (const uint8_t*)s_b4;
+
+  // ---- 1. stage kStageN bytes starting at cbase; bytes at or past data_len read as 0 ----
+  {
+    const uint8_t* g = stream + f.data_off + cbase;
+    const uint32_t mis = (uint32_t)((uintptr_t)g & 3u);
+    const uint32_t* g4 = (const uint32_t*)(g - mis);
+    for (int j = tid; j < kStageN / 4; j += kSumThreads) {
+      // LDS dword j = stream bytes cbase+4j .. +3 = aligned global dwords j, j+1 shifted by mis
+      const long long p0 = (long long)cbase + 4ll * j - (long long)mis;  // position of g4[j]'s first byte
+      uint32_t lo = 0, hi = 0;
+      if (p0 < (long long)f.data_len) lo = g4[j];
+      if (mis && p0 + 4 < (long long)f.data_len) hi = g4[j + 1];
+      uint32_t v = mis ? __builtin_amdgcn_alignbyte(hi, lo, mis) : lo;
+      const long long rem = (long long)f.data_len - ((long long)cbase + 4ll * j);
+      if (rem <= 0) v = 0;
+      else if (rem < 4) v &= (1u << (8 * (int)rem)) - 1u;
+      s_b4[j] = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- 2. inclusive prefix sum of token weights, 16 positions per thread ----
+  {
+    const uint4 q = ((const uint4*)s_b4)[tid];
+    const uint32_t d[4] = {q.x, q.y, q.z, q.w};
+    uint32_t loc[16];
+    uint32_t run = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      run += token_weight((d[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+      loc[i] = run;
+    }
+    const uint32_t incl = wave_incl_scan(run);
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    uint32_t off = incl - run;
+    for (int k = 0; k < wv; k++) off += s_wave[k];
+    uint32_t pk[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) pk[i] = ((loc[2 * i] + off) & 0xFFFFu) | ((loc[2 * i + 1] + off) << 16);
+    uint4* dst = (uint4*)(s_w + 16 * tid);
+    dst[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    dst[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+  }
+  __syncthreads();
+
+  // ---- 3. block length at every position, for both block types ----
+  const uint32_t lb8 = (uint32_t)lut[f.qidx].lb8, cb8 = (uint32_t)lut[f.qidx].cb8;
+  for (int i = tid; i < kTabN; i += kSumThreads) {
+    const uint32_t b0 = s_b[i];
+    uint32_t len[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const uint32_t bt8 = t ? cb8 : lb8, need = 63u - bt8;
+      const uint32_t iq = (uint32_t)i + bt8;  // last non-token byte
+      const uint32_t tgt = (uint32_t)s_w[iq] + need;
+      uint32_t lo = iq + 1u, hi = iq + need;  // the last token lies in [lo, hi] (weights are >= 1)
+#pragma unroll
+      for (int it = 0; it < 6; it++) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const bool ge = (((uint32_t)s_w[mid] - tgt) & 0x8000u) == 0u;  // sums differ by < 2^15
+        hi = ge ? mid : hi;
+        lo = ge ? lo : mid + 1u;
+      }
+      len[t] = need ? hi + 1u - (uint32_t)i : 64u;
+      if (b0 == 0xFFu) len[t] = 1u;
+    }
+    s_nl[i] = (uint8_t)len[0];
+    s_nc[i] = (uint8_t)len[1];
+  }
+  __syncthreads();
+
+  // ---- 4. macroblock length: four luma blocks then two chroma blocks ----
+  for (int p = tid; p < kChunk; p += kSumThreads) {
+    uint32_t q = p;
+    q += s_nl[q];
+    q += s_nl[q];
+    q += s_nl[q];
+    q += s_nl[q];
+    q += s_nc[q];
+    q += s_nc[q];
+    s_f[p] = (uint16_t)(q - p);
+  }
+  __syncthreads();
+
+  // ---- 5. walk every possible entry offset to the end of the chunk ----
+  uint32_t* out = summary + (size_t)(f.sum_base + c) * kEntries;
+  for (int e = tid; e < kEntries; e += kSumThreads) {
+    uint32_t p = e, cnt = 0;
+    while (p < (uint32_t)kChunk) {
+      p += s_f[p];
+      cnt++;
+    }
+    out[e] = (cnt << 16) | (p - (uint32_t)kChunk);
+  }
+}
+
+// One workgroup per packet.  Summaries are pulled through LDS a tile at a time; lane 0 chains them.
+constexpr int kResTile = 24;
+__global__ __launch_bounds__(256) void k_index_resolve(const FrameDev* __restrict__ frames,
+                                                        const uint32_t* __restrict__ summary,
+                                                        uint32_t* __restrict__ chunk_pos,
+                                                        uint32_t* __restrict__ chunk_mb) {
+  __shared__ uint32_t s_sum[kResTile * kEntries];
+  __shared__ uint32_t s_state[2];
+  const FrameDev f = frames[blockIdx.x];
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    s_state[0] = 0;  // entry offset into the current chunk
+    s_state[1] = 0;  // macroblocks before it
+  }
+  for (uint32_t c0 = 0; c0 < f.nchunks; c0 += kResTile) {
+    const uint32_t nt = min((uint32_t)kResTile, f.nchunks - c0);
+    __syncthreads();
+    const uint32_t* src = summary + (size_t)(f.sum_base + c0) * kEntries;
+    for (uint32_t i = tid; i < nt * kEntries; i += 256) s_sum[i] = src[i];
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t e = s_state[0], mb = s_state[1];
+      for (uint32_t j = 0; j < nt; j++) {
+        chunk_pos[f.chunk_base + c0 + j] = (c0 + j) * (uint32_t)kChunk + e;
+        chunk_mb[f.chunk_base + c0 + j] = min(mb, f.nmb);
+        const uint32_t v = s_sum[j * kEntries + e];
+        e = v & 0xFFFFu;
+        mb += v >> 16;
+      }
+      s_state[0] = e;
+      s_state[1] = mb;
+    }
+  }
+  // whatever the stream holds past the last macroblock is ignored; a packet that ends early is
+  // continued with zero bytes by the last chunk's walker
+  if (tid == 0) {
+    chunk_pos[f.chunk_base + f.nchunks] = 0;
+    chunk_mb[f.chunk_base + f.nchunks] = f.nmb;
+  }
+}
+
+// One wave per chunk: the serial walk, but only over the chunk's own blocks.
+__global__ __launch_bounds__(64) void k_index_emit(const FrameDev* __restrict__ frames,
+                                                    const uint8_t* __restrict__ stream,
+                                                    const QTab* __restrict__ lut,
+                                                    const uint32_t* __restrict__ chunk_pos,
+                                                    const uint32_t* __restrict__ chunk_mb,
+                                                    uint32_t* __restrict__ blkoff) {
+  const FrameDev f = frames[blockIdx.y];
+  const uint32_t c = blockIdx.x;
+  if (c >= f.nchunks) return;
+  const uint32_t m0 = chunk_mb[f.chunk_base + c];
+  const uint32_t m1 = chunk_mb[f.chunk_base + c + 1];  // == nmb for the last chunk
+  if (m0 >= m1) return;
+  walk_blocks(f, stream, lut, chunk_pos[f.chunk_base + c], 6u * m0, 6u * m1, m1 == f.nmb, blkoff + f.blk_base);
+}
+
+}  // namespace mirtj

@@ -88,10 +88,17 @@ int mi_rtj_plan_decode(mi_rtj_plan *plan, const void *d_stream, void *d_out);
 void mi_rtj_plan_info(const mi_rtj_plan *plan, int *n_frames, uint64_t *n_blocks,
                       uint64_t *bytes_in, uint64_t *bytes_out);
 /* Per-kernel device time: when enabled, mi_rtj_plan_decode brackets each kernel with HIP events
- * on the launch stream.  mi_rtj_plan_times sums them since the last reset (after a sync):
- * ms[0] = index kernel(s), ms[1] = decode kernel, launches = number of mi_rtj_plan_decode calls. */
+ * on the launch stream.  mi_rtj_plan_times sums them since the last reset (after a sync), one
+ * slot per kernel of the path; launches = number of mi_rtj_plan_decode calls summed. */
+enum {
+  MI_RTJ_K_SUMMARIZE = 0, /* k_index_summarize: per-chunk block-length tables + entry summaries */
+  MI_RTJ_K_RESOLVE = 1,   /* k_index_resolve: chain the summaries per packet */
+  MI_RTJ_K_EMIT = 2,      /* k_index_emit (or k_index_walk with MI_RTJ_INDEX=serial): block offsets */
+  MI_RTJ_K_DECODE = 3,    /* k_decode: dequant + IDCT + plane scatter */
+  MI_RTJ_NUM_KERNELS = 4
+};
 void mi_rtj_plan_profile(mi_rtj_plan *plan, int enable);
-int mi_rtj_plan_times(mi_rtj_plan *plan, float ms[2], int *launches);
+int mi_rtj_plan_times(mi_rtj_plan *plan, float ms[MI_RTJ_NUM_KERNELS], int *launches);
 /* Test hook: copy the plan's block-start index (relative to each packet's first data byte,
  * nblocks+1 entries per frame, frames back to back) to the host after a decode. */
 int mi_rtj_plan_read_index(mi_rtj_plan *plan, uint32_t *dst, size_t max_entries);

@@ -221,6 +221,65 @@ def test_crop_and_strides_like_gavl_frame_copy(dev):
     d.close()
 
 
+def test_serial_and_parallel_index_agree(dev, monkeypatch):
+    """MI_RTJ_INDEX=serial keeps the one-wave-per-packet walker as an A/B baseline of the
+    chunk-parallel index; both must produce the oracle's offsets (batch_decode checks them)."""
+    w, h = 640, 368
+    pkts = [R.OracleEncoder(w, h, Q).encode(R.synth_frame(w, h, i, seed=4, amp=a))
+            for i, (Q, a) in enumerate([(255, 8), (255, 64), (40, 64), (128, 0), (200, 120)])]
+    inter = R.OracleEncoder(w, h, 180, key_rate=3, lmask=4, cmask=4)
+    pkts += [inter.encode(R.synth_frame(w, h, n // 2, seed=8, amp=3)) for n in range(4)]
+    want = []
+    for p in pkts:
+        o = np.zeros(frame_bytes(w, h), np.uint8)
+        R.OracleDecoder().decode(p, o)
+        want.append(o)
+    for mode in ("serial", "parallel"):
+        monkeypatch.setenv("MI_RTJ_INDEX", mode)
+        outs = batch_decode(dev, pkts)
+        for o, wnt in zip(outs, want):
+            assert first_diff(o, wnt) is None, mode
+
+
+def test_chunk_boundaries_and_long_blocks(dev):
+    """Streams built to stress the chunked index: maximal 64-byte blocks (no zero runs), minimal
+    1-byte (0xFF) blocks, and mixtures, so macroblocks straddle every chunk boundary differently."""
+    rng = np.random.default_rng(77)
+    w, h = 1024, 256  # 1024 macroblocks: long-block packets span ~110 chunks
+    nblk = (w // 16) * (h // 16) * 6
+    pkts = []
+    for Q, mode in [(255, "long"), (255, "skip"), (255, "mix"), (100, "long"), (100, "mix"), (255, "runs")]:
+        _, _, lb8, cb8, _, _ = R.oracle_tables(Q)
+        body = bytearray()
+        for b in range(nblk):
+            bt8 = lb8 if (b % 6) < 4 else cb8
+            kind = mode if mode != "mix" else ["long", "skip", "short", "runs"][int(rng.integers(0, 4))]
+            if kind == "skip":
+                body.append(255)
+                continue
+            blk = [int(rng.integers(0, 255))] + [int(x) for x in rng.integers(0, 256, bt8)]
+            left = 63 - bt8
+            if kind == "long":      # every remaining coefficient spelled out
+                blk += [int(x) & 0xFF for x in rng.integers(-64, 64, left)]
+            elif kind == "short":   # one run to the end
+                blk.append(63 + left)
+            else:                   # unit runs: many weight-1 run tokens (byte 64)
+                while left > 0:
+                    r = int(rng.integers(1, min(left, 3) + 1))
+                    blk.append(63 + r)
+                    left -= r
+            body += bytes(blk)
+        total = 12 + len(body)
+        hdr = bytes([total & 255, (total >> 8) & 255, (total >> 16) & 255, (total >> 24) & 255, 12, 0,
+                     w & 255, w >> 8, h & 255, h >> 8, Q, 0])
+        pkts.append(np.frombuffer(hdr + bytes(body), dtype=np.uint8).copy())
+    outs = batch_decode(dev, pkts, prefill=3)
+    for p, got in zip(pkts, outs):
+        want = np.full(frame_bytes(w, h), 3, np.uint8)
+        R.OracleDecoder().decode(p, want)
+        assert first_diff(got, want) is None
+
+
 # --------------------------------------------------------------------------- generator side (N1)
 @pytest.mark.parametrize("w,h,amp", [(64, 48, 8), (320, 240, 64), (1920, 1088, 8)])
 def test_synth_matches_numpy_twin(dev, w, h, amp):
