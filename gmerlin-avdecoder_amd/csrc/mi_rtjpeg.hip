@@ -55,6 +55,7 @@ struct mi_rtj_plan {
   FrameDev* d_frames = nullptr;
   uint32_t* d_blkoff = nullptr;
   uint32_t* d_summary = nullptr;    // [total chunks][kEntries]
+  uint16_t* d_lentab = nullptr;     // [total chunks][kChunk] block lengths (luma | chroma << 8)
   uint32_t* d_chunk_pos = nullptr;  // [total chunks + n]
   uint32_t* d_chunk_mb = nullptr;
   uint64_t n_blocks = 0, n_index = 0, bytes_in = 0, bytes_out = 0;
@@ -62,6 +63,7 @@ struct mi_rtj_plan {
   uint32_t max_groups = 0, max_chunks = 0;
   bool profile = false;
   bool serial_index = false;        // MI_RTJ_INDEX=serial: one wave per packet (A/B baseline)
+  bool emit_walk = false;           // MI_RTJ_EMIT=walk: per-chunk re-walk instead of the length tables
   std::vector<Timed> ev[MI_RTJ_NUM_KERNELS];  // one pair per launch while profiling
   int launches = 0;
 };
@@ -147,9 +149,12 @@ int plan_alloc_chunks(mi_rtj_plan* p) {
     if (p->d_summary) {
       HIPCHK(c, hipStreamSynchronize(c->stream));
       (void)hipFree(p->d_summary);
+      (void)hipFree(p->d_lentab);
       p->d_summary = nullptr;
+      p->d_lentab = nullptr;
     }
     HIPCHK(c, hipMalloc((void**)&p->d_summary, sizeof(uint32_t) * kEntries * chunks));
+    HIPCHK(c, hipMalloc((void**)&p->d_lentab, sizeof(uint16_t) * kChunk * chunks + 64));
     p->n_chunks = chunks;
   }
   if (entries > p->n_chunk_entries) {
@@ -199,19 +204,23 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
   } else {
     if ((rc = begin(MI_RTJ_K_SUMMARIZE)) != MI_RTJ_OK) return rc;
     hipLaunchKernelGGL(k_index_summarize, dim3(p->max_chunks, p->n), dim3(kSumThreads), 0, c->stream, p->d_frames, st,
-                       c->d_lut, p->d_summary);
+                       c->d_lut, p->d_summary, p->d_lentab);
     if ((rc = end(MI_RTJ_K_SUMMARIZE)) != MI_RTJ_OK) return rc;
     if ((rc = begin(MI_RTJ_K_RESOLVE)) != MI_RTJ_OK) return rc;
     hipLaunchKernelGGL(k_index_resolve, dim3(p->n), dim3(256), 0, c->stream, p->d_frames, p->d_summary,
                        p->d_chunk_pos, p->d_chunk_mb);
     if ((rc = end(MI_RTJ_K_RESOLVE)) != MI_RTJ_OK) return rc;
     if ((rc = begin(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
-    hipLaunchKernelGGL(k_index_emit, dim3(p->max_chunks, p->n), dim3(64), 0, c->stream, p->d_frames, st, c->d_lut,
-                       p->d_chunk_pos, p->d_chunk_mb, p->d_blkoff);
+    if (p->emit_walk)
+      hipLaunchKernelGGL(k_index_emit_walk, dim3(p->max_chunks, p->n), dim3(64), 0, c->stream, p->d_frames, st,
+                         c->d_lut, p->d_chunk_pos, p->d_chunk_mb, p->d_blkoff);
+    else
+      hipLaunchKernelGGL(k_index_emit, dim3(p->max_chunks, p->n), dim3(kEmitThreads), 0, c->stream, p->d_frames,
+                         p->d_lentab, p->d_chunk_pos, p->d_chunk_mb, p->d_blkoff);
     if ((rc = end(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
   }
   if ((rc = begin(MI_RTJ_K_DECODE)) != MI_RTJ_OK) return rc;
-  hipLaunchKernelGGL(k_decode, dim3(p->max_groups, p->n), dim3(kDecThreads), 0, c->stream, p->d_frames, st, c->d_lut,
+  hipLaunchKernelGGL(k_decode, dim3(p->max_groups * 3, p->n), dim3(kDecThreads), 0, c->stream, p->d_frames, st, c->d_lut,
                      p->d_blkoff, (uint8_t*)d_out);
   if ((rc = end(MI_RTJ_K_DECODE)) != MI_RTJ_OK) return rc;
   HIPCHK(c, hipGetLastError());
@@ -389,6 +398,8 @@ mi_rtj_plan* mi_rtj_plan_create(mi_rtj_ctx* c, int n, const uint8_t* headers, co
   {
     const char* mode = getenv("MI_RTJ_INDEX");
     p->serial_index = mode && strcmp(mode, "serial") == 0;
+    const char* em = getenv("MI_RTJ_EMIT");
+    p->emit_walk = em && strcmp(em, "walk") == 0;
   }
   if (hipSetDevice(c->device) != hipSuccess || plan_alloc_chunks(p) != MI_RTJ_OK) {
     mi_rtj_plan_destroy(p);
@@ -415,6 +426,7 @@ void mi_rtj_plan_destroy(mi_rtj_plan* p) {
   if (p->d_frames) (void)hipFree(p->d_frames);
   if (p->d_blkoff) (void)hipFree(p->d_blkoff);
   if (p->d_summary) (void)hipFree(p->d_summary);
+  if (p->d_lentab) (void)hipFree(p->d_lentab);
   if (p->d_chunk_pos) (void)hipFree(p->d_chunk_pos);
   if (p->d_chunk_mb) (void)hipFree(p->d_chunk_mb);
   delete p;
@@ -529,6 +541,8 @@ int mi_rtj_decode(mi_rtj_ctx* c, const uint8_t* pkt, size_t len, uint8_t* const 
     if (rc2 != MI_RTJ_OK) return rc2;
     const char* mode = getenv("MI_RTJ_INDEX");
     p->serial_index = mode && strcmp(mode, "serial") == 0;
+    const char* em = getenv("MI_RTJ_EMIT");
+    p->emit_walk = em && strcmp(em, "walk") == 0;
   }
   HIPCHK(c, hipMemcpyAsync(c->d_pkt, pkt, len, hipMemcpyHostToDevice, c->stream));
   int r = plan_upload(p);

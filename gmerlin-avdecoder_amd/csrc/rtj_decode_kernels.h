@@ -154,6 +154,12 @@ __device__ __forceinline__ int mulr8(int x, int c) {
   return r >> 8;
 }
 
+__device__ __forceinline__ int mul24(int a, int b) {  // both operands inside the signed 24-bit range
+  int r;
+  asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 __device__ __forceinline__ void idct8(int x0, int x1, int x2, int x3, int x4, int x5, int x6, int x7,
                                       int (&y)[8]) {
   const int s04 = x0 + x4, d04 = x0 - x4;
@@ -183,106 +189,112 @@ __device__ __forceinline__ uint32_t px(int v) {
   return (uint32_t)s;
 }
 
-constexpr int kDecThreads = 192;
-constexpr int kCoefStride = 72;                 // int16 per lane: 64 + 8 pad (144 B, conflict-free b128 reads)
-constexpr int kStreamCap = kMbPerGroup * 6 * 64; // worst-case bytes of one macroblock group
+constexpr int kDecThreads = 64;
+constexpr int kCoefStride = 72;  // int16 per lane: 64 + 8 pad (144 B, conflict-free b128 reads)
 
 // ---------------------------------------------------------------------------------------
-// k_decode: grid (groups, frames); a workgroup owns kMbPerGroup consecutive macroblocks.
-//   wave 0: the 64 upper luma blocks (Y0,Y1 of each MB), wave 1: the 64 lower ones,
-//   wave 2: 32 Cb + 32 Cr blocks.  Lanes of a wave hold horizontally adjacent blocks, so
-//   every row store of a wave covers 512 (luma) or 2x256 (chroma) contiguous bytes.
-// The group's slice of the stream is staged in LDS, each lane parses its own block into a
-// private LDS scratch (transposed, so a column is one 16-byte read), then runs both
-// transform passes entirely in registers.
+// k_decode: grid (3 * groups, frames), one wave per workgroup.  A group is kMbPerGroup
+// consecutive macroblocks; its three waves take
+//   part 0: the 64 upper luma blocks (Y0,Y1 of each MB), part 1: the 64 lower ones,
+//   part 2: 32 Cb + 32 Cr blocks.
+// Lanes of a wave hold horizontally adjacent blocks, so every row store of a wave covers 512
+// (luma) or 2x256 (chroma) contiguous bytes.  Each lane pulls its own block's bytes from the
+// stream (neighbouring lanes read neighbouring bytes, so the wave's loads stay within a few
+// cache lines), parses them into a private LDS scratch (transposed, so a column is one 16-byte
+// read), then runs both transform passes entirely in registers.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kDecThreads) void k_decode(const FrameDev* __restrict__ frames,
                                                          const uint8_t* __restrict__ stream,
                                                          const QTab* __restrict__ lut,
                                                          const uint32_t* __restrict__ blkoff,
                                                          uint8_t* __restrict__ outbuf) {
-  __shared__ __attribute__((aligned(16))) uint32_t s_stream[kStreamCap / 4 + 4];
   __shared__ __attribute__((aligned(16))) int16_t s_coef[kDecThreads * kCoefStride];
-  __shared__ uint32_t s_tab[2][64];  // per zig-zag slot: (dequantiser << 8) | transposed position
+  __shared__ uint32_t s_tab[64];  // per zig-zag slot: (dequantiser << 8) | transposed position
 
   const FrameDev f = frames[blockIdx.y];
-  const uint32_t mb0 = blockIdx.x * kMbPerGroup;
+  const uint32_t grp = blockIdx.x / 3u, part = blockIdx.x - 3u * grp;
+  const uint32_t mb0 = grp * kMbPerGroup;
   if (mb0 >= f.nmb) return;
-  const int tid = threadIdx.x;
+  const int lane = threadIdx.x;
   const uint32_t mb_end = min(mb0 + (uint32_t)kMbPerGroup, f.nmb);
   const uint32_t* off = blkoff + f.blk_base;
   const QTab& qt = lut[f.qidx];
-
-  if (tid < 128) {
-    const int t = tid >> 6, co = tid & 63;
-    const int nat = c_zz[co];
-    const int q = t ? qt.ciqt[nat] : qt.liqt[nat];
-    s_tab[t][co] = ((uint32_t)q << 8) | (uint32_t)((nat & 7) * 8 + (nat >> 3));
+  const int chroma = part == 2u;
+  {
+    const int nat = c_zz[lane];
+    const int q = chroma ? qt.ciqt[nat] : qt.liqt[nat];
+    s_tab[lane] = ((uint32_t)q << 8) | (uint32_t)((nat & 7) * 8 + (nat >> 3));
   }
-
-  // ---- stage the group's bytes: [start, end) relative to the first data byte ----
-  const uint32_t start = off[6u * mb0], end = off[6u * mb_end];
-  const uint8_t* gsrc = stream + f.data_off + start;
-  const uint32_t mis = (uint32_t)((uintptr_t)gsrc & 3u);
-  const uint32_t* g4 = (const uint32_t*)(gsrc - mis);
-  const uint32_t ndw = (end - start + mis + 3u) >> 2;
-  for (uint32_t j = tid; j < ndw; j += kDecThreads) {
-    const long long rel = (long long)start - (long long)mis + 4ll * j;  // of the dword's first byte
-    uint32_t v = 0;
-    if (rel < (long long)f.data_len) {
-      v = g4[j];
-      const long long rem = (long long)f.data_len - rel;
-      if (rem < 4) v &= (1u << (8 * (int)rem)) - 1u;  // bytes at or past the end read as 0
-    }
-    s_stream[j] = v;
-  }
-  __syncthreads();
+  __syncthreads();  // one wave: orders the table write before the lanes' reads
+  const uint32_t bt8 = (uint32_t)(chroma ? qt.cb8 : qt.lb8);
 
   // ---- which block is mine ----
-  const int wv = tid >> 6, lane = tid & 63;
   uint32_t mb, kblk;
-  if (wv < 2) {
+  if (!chroma) {
     mb = mb0 + (lane >> 1);
-    kblk = 2u * wv + (lane & 1);
+    kblk = 2u * part + (lane & 1);
   } else {
     mb = mb0 + (lane & 31);
     kblk = 4u + (lane >> 5);
   }
   if (mb >= mb_end) return;  // no barriers below
-  const int chroma = kblk >= 4u;
-  const uint32_t bt8 = (uint32_t)(chroma ? qt.cb8 : qt.lb8);
-  const uint8_t* sb = (const uint8_t*)s_stream + mis;
-  uint32_t ci = off[6u * mb + kblk] - start;
-  const uint32_t b0 = sb[ci++];
-  if (b0 == 0xFFu) return;  // unchanged block: previous pixels stay (lib/RTjpeg.c:2704)
 
   // ---- stream -> dequantised coefficients, int16, transposed (lib/RTjpeg.c:157-186) ----
-  int16_t* my = s_coef + tid * kCoefStride;
+  // The block's bytes are pulled 16 at a time into registers (aligned dwords + a byte funnel
+  // shift), so the only loop-carried dependency is the coefficient counter; table reads and
+  // scratch writes of the 16 byte slots are independent and pipeline through the LDS.
+  // Bytes at or past data_len read as 0.
+  const uint32_t pos0 = off[6u * mb + kblk];  // block start relative to the first data byte
+  const uint8_t* gsrc = stream + f.data_off + pos0;
+  const uint32_t sh = (uint32_t)((uintptr_t)gsrc & 3u);
+  const uint32_t* g4 = (const uint32_t*)(gsrc - sh);
+  long long rel = (long long)pos0 - (long long)sh;  // position of g4[0]'s first byte
+  auto ld = [&](int k) -> uint32_t {
+    const long long r = rel + 4ll * k, rem = (long long)f.data_len - r;
+    uint32_t v = 0;
+    if (rem > 0) {
+      v = g4[k];
+      if (rem < 4) v &= (1u << (8 * (int)rem)) - 1u;
+    }
+    return v;
+  };
+  uint32_t d0 = ld(0), d1 = ld(1), d2 = ld(2), d3 = ld(3), d4 = ld(4);
+  if ((__builtin_amdgcn_alignbyte(d1, d0, sh) & 0xFFu) == 0xFFu) return;  // unchanged block (lib/RTjpeg.c:2704)
+
+  int16_t* my = s_coef + lane * kCoefStride;
   {
     uint4* z = (uint4*)my;
 #pragma unroll
     for (int i = 0; i < 8; i++) z[i] = make_uint4(0, 0, 0, 0);
   }
-  const uint32_t* tab = s_tab[chroma];
-  {
-    const uint32_t e = tab[0];
-    my[e & 63u] = (int16_t)(b0 * (e >> 8));  // DC is the only unsigned byte
-  }
-  uint32_t co = 1;
-  for (; co <= bt8; co++) {
-    const int v = (int8_t)sb[ci++];
-    const uint32_t e = tab[co];
-    my[e & 63u] = (int16_t)(v * (int)(e >> 8));
-  }
-  while (co < 64u) {
-    const int v = (int8_t)sb[ci++];
-    if (v > 63) {
-      co += (uint32_t)(v - 63);  // zero run; the scratch is already zero
-    } else {
-      const uint32_t e = tab[co];
-      my[e & 63u] = (int16_t)(v * (int)(e >> 8));
-      co++;
+  const uint32_t* tab = s_tab;
+  uint32_t co = 0;    // next coefficient slot (zig-zag index)
+  uint32_t jbase = 0; // index of the round's first byte within the block
+  while (true) {
+    const uint32_t wd[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
+                            __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+      const uint32_t j = jbase + t;
+      const uint32_t ub = (wd[t >> 2] >> (8 * (t & 3))) & 0xFFu;
+      const int sv = (int)(int8_t)ub;
+      const int val = j == 0u ? (int)ub : sv;              // DC is the only unsigned byte
+      const bool run = j > bt8 && sv > 63;                 // zero run of sv-63 slots (scratch is already 0)
+      const bool live = co < 64u;
+      const uint32_t e = tab[co & 63u];
+      const int prod = mul24(val, (int)(e >> 8));          // |val| < 2^8, dequantiser < 2^15
+      my[(live && !run) ? (e & 63u) : 64u] = (int16_t)prod;  // slot 64 is a write-only dump
+      co += run ? (uint32_t)(sv - 63) : 1u;
     }
+    if (!__any(co < 64u)) break;
+    jbase += 16u;
+    g4 += 4;
+    rel += 16;
+    d0 = d4;
+    d1 = ld(1);
+    d2 = ld(2);
+    d3 = ld(3);
+    d4 = ld(4);
   }
 
   // ---- column pass: column c of the block is the c-th 16-byte piece of the scratch ----
@@ -302,7 +314,22 @@ __global__ __launch_bounds__(kDecThreads) void k_decode(const FrameDev* __restri
   }
 
   // ---- row pass + scatter ----
-  const uint32_t mx = mb % f.mbw, my_ = mb / f.mbw;
+  // macroblock coordinates without a per-lane division: one scalar division for the group's
+  // first macroblock, then at most one row wrap per lane when rows are at least a group wide
+  uint32_t mx, my_;
+  {
+    const uint32_t mbw = f.mbw;
+    const uint32_t gy = mb0 / mbw, gx = mb0 - gy * mbw;  // uniform
+    const uint32_t dx = mb - mb0;
+    if (mbw >= (uint32_t)kMbPerGroup) {
+      const bool wrap = gx + dx >= mbw;
+      mx = wrap ? gx + dx - mbw : gx + dx;
+      my_ = wrap ? gy + 1u : gy;
+    } else {
+      my_ = mb / mbw;
+      mx = mb - my_ * mbw;
+    }
+  }
   uint8_t* dst;
   uint32_t stride;
   if (!chroma) {
@@ -320,7 +347,8 @@ __global__ __launch_bounds__(kDecThreads) void k_decode(const FrameDev* __restri
     uint2 o;
     o.x = px(y[0]) | (px(y[1]) << 8) | (px(y[2]) << 16) | (px(y[3]) << 24);
     o.y = px(y[4]) | (px(y[5]) << 8) | (px(y[6]) << 16) | (px(y[7]) << 24);
-    *(uint2*)(dst + (size_t)r * stride) = o;
+    *(uint2*)dst = o;
+    dst += stride;
   }
 }
 

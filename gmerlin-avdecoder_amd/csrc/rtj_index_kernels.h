@@ -29,10 +29,12 @@ constexpr int kSumThreads = 256;
 __global__ __launch_bounds__(kSumThreads) void k_index_summarize(const FrameDev* __restrict__ frames,
                                                                   const uint8_t* __restrict__ stream,
                                                                   const QTab* __restrict__ lut,
-                                                                  uint32_t* __restrict__ summary) {
+                                                                  uint32_t* __restrict__ summary,
+                                                                  uint16_t* __restrict__ lentab) {
   __shared__ __attribute__((aligned(16))) uint32_t s_b4[kStageN / 4];  // stream bytes
   __shared__ __attribute__((aligned(16))) uint16_t s_w[kStageN];       // inclusive weight sums mod 2^16
-  __shared__ uint8_t s_nl[kTabN], s_nc[kTabN];                         // block length if luma / chroma
+  __shared__ __attribute__((aligned(16))) uint8_t s_nl[kTabN];         // block length if luma ...
+  __shared__ __attribute__((aligned(16))) uint8_t s_nc[kTabN];         // ... or chroma
   __shared__ uint16_t s_f[kChunk];                                     // macroblock length
   __shared__ uint32_t s_wave[kSumThreads / 64];
 
@@ -114,6 +116,20 @@ __global__ __launch_bounds__(kSumThreads) void k_index_summarize(const FrameDev*
   }
   __syncthreads();
 
+  // both lengths of the chunk's own positions go to HBM for k_index_emit: (luma | chroma << 8)
+  {
+    uint4* dst = (uint4*)(lentab + (size_t)(f.sum_base + c) * kChunk);
+    for (int i = tid; i < kChunk / 8; i += kSumThreads) {
+      const uint2 l = ((const uint2*)s_nl)[i], h = ((const uint2*)s_nc)[i];
+      uint4 o;
+      o.x = __builtin_amdgcn_perm(h.x, l.x, 0x05010400u);  // bytes l0 h0 l1 h1
+      o.y = __builtin_amdgcn_perm(h.x, l.x, 0x07030602u);  //       l2 h2 l3 h3
+      o.z = __builtin_amdgcn_perm(h.y, l.y, 0x05010400u);
+      o.w = __builtin_amdgcn_perm(h.y, l.y, 0x07030602u);
+      dst[i] = o;
+    }
+  }
+
   // ---- 4. macroblock length: four luma blocks then two chroma blocks ----
   for (int p = tid; p < kChunk; p += kSumThreads) {
     uint32_t q = p;
@@ -180,8 +196,9 @@ __global__ __launch_bounds__(256) void k_index_resolve(const FrameDev* __restric
   }
 }
 
-// One wave per chunk: the serial walk, but only over the chunk's own blocks.
-__global__ __launch_bounds__(64) void k_index_emit(const FrameDev* __restrict__ frames,
+// A/B baseline of k_index_emit (MI_RTJ_EMIT=walk): one wave per chunk re-walks the chunk's own
+// blocks from the stream bytes.
+__global__ __launch_bounds__(64) void k_index_emit_walk(const FrameDev* __restrict__ frames,
                                                     const uint8_t* __restrict__ stream,
                                                     const QTab* __restrict__ lut,
                                                     const uint32_t* __restrict__ chunk_pos,
@@ -194,6 +211,89 @@ __global__ __launch_bounds__(64) void k_index_emit(const FrameDev* __restrict__ 
   const uint32_t m1 = chunk_mb[f.chunk_base + c + 1];  // == nmb for the last chunk
   if (m0 >= m1) return;
   walk_blocks(f, stream, lut, chunk_pos[f.chunk_base + c], 6u * m0, 6u * m1, m1 == f.nmb, blkoff + f.blk_base);
+}
+
+// k_index_emit: per chunk, from the block lengths k_index_summarize left in HBM and the true
+// entry k_index_resolve found: macroblock lengths in parallel, one short serial walk over the
+// chunk's macroblocks, then the six block offsets of every macroblock in parallel.
+constexpr int kEmitThreads = 256;
+constexpr int kMaxMbPerChunk = kChunk / 6 + 2;  // a macroblock is at least six 1-byte blocks
+__global__ __launch_bounds__(kEmitThreads) void k_index_emit(const FrameDev* __restrict__ frames,
+                                                              const uint16_t* __restrict__ lentab,
+                                                              const uint32_t* __restrict__ chunk_pos,
+                                                              const uint32_t* __restrict__ chunk_mb,
+                                                              uint32_t* __restrict__ blkoff) {
+  __shared__ __attribute__((aligned(16))) uint16_t s_len[kTabN + 8];  // (luma | chroma << 8) per position
+  __shared__ uint16_t s_f[kChunk];
+  __shared__ uint16_t s_mb[kMaxMbPerChunk];
+  __shared__ uint32_t s_cnt[2];
+
+  const FrameDev f = frames[blockIdx.y];
+  const uint32_t c = blockIdx.x;
+  if (c >= f.nchunks) return;
+  const uint32_t m0 = chunk_mb[f.chunk_base + c];
+  const uint32_t m1 = chunk_mb[f.chunk_base + c + 1];  // == nmb for the last chunk
+  if (m0 >= m1) return;
+  const int tid = threadIdx.x;
+  const uint32_t cbase = c * (uint32_t)kChunk;
+  const uint32_t q0 = chunk_pos[f.chunk_base + c] - cbase;  // entry offset, < kEntries
+  uint32_t* out = blkoff + f.blk_base;
+
+  // ---- block lengths of [cbase, cbase + kTabN); past the packet's last chunk every byte is 0,
+  //      and a block of zero bytes is 64 bytes long whatever its type ----
+  {
+    const size_t have = (size_t)(f.nchunks - c) * kChunk;  // table entries from cbase to the end of the packet
+    const uint4* src = (const uint4*)(lentab + (size_t)(f.sum_base + c) * kChunk);
+    for (int i = tid; i < (kTabN + 7) / 8; i += kEmitThreads) {
+      uint4 v = make_uint4(0x40404040u, 0x40404040u, 0x40404040u, 0x40404040u);
+      if ((size_t)i * 8 + 8 <= have) v = src[i];  // kChunk is a multiple of 8, so no piece straddles the end
+      ((uint4*)s_len)[i] = v;
+    }
+  }
+  __syncthreads();
+  for (int p = tid; p < kChunk; p += kEmitThreads) {
+    uint32_t q = p;
+    q += s_len[q] & 0xFFu;
+    q += s_len[q] & 0xFFu;
+    q += s_len[q] & 0xFFu;
+    q += s_len[q] & 0xFFu;
+    q += s_len[q] >> 8;
+    q += s_len[q] >> 8;
+    s_f[p] = (uint16_t)(q - p);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t q = q0, n = 0;
+    const uint32_t want = m1 - m0;
+    while (q < (uint32_t)kChunk && n < want) {
+      s_mb[n++] = (uint16_t)q;
+      q += s_f[q];
+    }
+    s_cnt[0] = n;  // macroblocks that start inside the chunk
+    s_cnt[1] = q;  // where the next one starts
+  }
+  __syncthreads();
+  const uint32_t n_in = s_cnt[0], q_end = s_cnt[1];
+  for (uint32_t i = tid; i < n_in; i += kEmitThreads) {
+    uint32_t q = s_mb[i];
+    uint32_t* o = out + 6u * (m0 + i);
+    o[0] = cbase + q;
+    q += s_len[q] & 0xFFu;
+    o[1] = cbase + q;
+    q += s_len[q] & 0xFFu;
+    o[2] = cbase + q;
+    q += s_len[q] & 0xFFu;
+    o[3] = cbase + q;
+    q += s_len[q] & 0xFFu;
+    o[4] = cbase + q;
+    q += s_len[q] >> 8;
+    o[5] = cbase + q;
+  }
+  // Macroblocks the packet does not hold any more (it ended early): only the last chunk gets
+  // here with m0 + n_in < m1, and from q_end on every byte reads as 0: 64-byte blocks.
+  const uint32_t n_tail = (m1 - m0) - n_in;
+  for (uint32_t i = tid; i < n_tail * 6u; i += kEmitThreads) out[6u * (m0 + n_in) + i] = cbase + q_end + 64u * i;
+  if (tid == 0 && m1 == f.nmb) out[6u * f.nmb] = cbase + q_end + 384u * n_tail;
 }
 
 }  // namespace mirtj
