@@ -18,7 +18,8 @@ class MiRtjError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(HERE, "lib", "libmi_rtjpeg.so")
+    # MI_RTJ_LIB: an alternative build of the same library (A/B experiments under tools/)
+    return os.environ.get("MI_RTJ_LIB") or os.path.join(HERE, "lib", "libmi_rtjpeg.so")
 
 
 EXPORTS = ["mi_rtj_device_count", "mi_rtj_create", "mi_rtj_destroy", "mi_rtj_last_error", "mi_rtj_decode",

@@ -12,8 +12,13 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmi_rtjpeg.so")
 SOURCES = ["mi_rtjpeg.hip", "rtj_tables.cpp"]
-HEADERS = ["rtj_common.h", "rtj_tables.h", "rtj_decode_kernels.h", "rtj_encode_kernels.h",
-           os.path.join("..", "..", "include", "mi_rtjpeg.h")]
+import glob
+
+
+def _deps():
+    d = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "*.hip")) + \
+        glob.glob(os.path.join(CSRC, "*.cpp")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    return d
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
@@ -21,21 +26,22 @@ def stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return any(os.path.getmtime(f) > t for f in _deps())
 
 
-def build(force=False, verbose=False):
-    if not force and not stale():
+def build(force=False, verbose=False, out=None):
+    if not force and not stale() and out is None:
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
+    extra = os.environ.get("MI_RTJ_CFLAGS", "").split()
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-Wno-unused-function"] + extra + ["-o", out or LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
-    return LIB
+    return out or LIB
 
 
 if __name__ == "__main__":

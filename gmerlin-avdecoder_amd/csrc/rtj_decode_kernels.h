@@ -190,7 +190,13 @@ __device__ __forceinline__ uint32_t px(int v) {
 }
 
 constexpr int kDecThreads = 64;
-constexpr int kCoefStride = 72;  // int16 per lane: 64 + 8 pad (144 B, conflict-free b128 reads)
+#ifndef MIRTJ_COEF_STRIDE
+#define MIRTJ_COEF_STRIDE 72
+#endif
+#ifndef MIRTJ_DEC_WAVES
+#define MIRTJ_DEC_WAVES 1
+#endif
+constexpr int kCoefStride = MIRTJ_COEF_STRIDE;  // int16 per lane: 64 + 8 pad (144 B, conflict-free b128 reads)
 
 // ---------------------------------------------------------------------------------------
 // k_decode: grid (3 * groups, frames), one wave per workgroup.  A group is kMbPerGroup
@@ -203,7 +209,7 @@ constexpr int kCoefStride = 72;  // int16 per lane: 64 + 8 pad (144 B, conflict-
 // cache lines), parses them into a private LDS scratch (transposed, so a column is one 16-byte
 // read), then runs both transform passes entirely in registers.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kDecThreads) void k_decode(const FrameDev* __restrict__ frames,
+__global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const FrameDev* __restrict__ frames,
                                                          const uint8_t* __restrict__ stream,
                                                          const QTab* __restrict__ lut,
                                                          const uint32_t* __restrict__ blkoff,
@@ -270,6 +276,41 @@ __global__ __launch_bounds__(kDecThreads) void k_decode(const FrameDev* __restri
   const uint32_t* tab = s_tab;
   uint32_t co = 0;    // next coefficient slot (zig-zag index)
   uint32_t jbase = 0; // index of the round's first byte within the block
+#ifdef MIRTJ_DECODE_HALVES  // measured slower than plain 16-byte rounds: off
+  while (true) {
+    const uint32_t wd[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
+                            __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
+    // the next 16 bytes are requested before these are consumed (luma blocks average ~17 bytes)
+    g4 += 4;
+    rel += 16;
+    d0 = d4;
+    d1 = ld(1);
+    d2 = ld(2);
+    d3 = ld(3);
+    d4 = ld(4);
+    bool more = true;
+#pragma unroll
+    for (int half = 0; half < 2 && more; half++) {
+#pragma unroll
+      for (int t = 8 * half; t < 8 * half + 8; t++) {
+        const uint32_t j = jbase + t;
+        const uint32_t ub = (wd[t >> 2] >> (8 * (t & 3))) & 0xFFu;
+        const int sv = (int)(int8_t)ub;
+        const int val = j == 0u ? (int)ub : sv;              // DC is the only unsigned byte
+        const bool run = j > bt8 && sv > 63;                 // zero run of sv-63 slots (scratch is already 0)
+        const bool live = co < 64u;
+        const uint32_t e = tab[co & 63u];
+        const int prod = mul24(val, (int)(e >> 8));          // |val| < 2^8, dequantiser < 2^15
+        my[(live && !run) ? (e & 63u) : 64u] = (int16_t)prod;  // slot 64 is a write-only dump
+        co += run ? (uint32_t)(sv - 63) : 1u;
+      }
+      more = __any(co < 64u);
+    }
+    if (!more) break;
+    jbase += 16u;
+  }
+
+#else
   while (true) {
     const uint32_t wd[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
                             __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
@@ -278,12 +319,12 @@ __global__ __launch_bounds__(kDecThreads) void k_decode(const FrameDev* __restri
       const uint32_t j = jbase + t;
       const uint32_t ub = (wd[t >> 2] >> (8 * (t & 3))) & 0xFFu;
       const int sv = (int)(int8_t)ub;
-      const int val = j == 0u ? (int)ub : sv;              // DC is the only unsigned byte
-      const bool run = j > bt8 && sv > 63;                 // zero run of sv-63 slots (scratch is already 0)
+      const int val = j == 0u ? (int)ub : sv;
+      const bool run = j > bt8 && sv > 63;
       const bool live = co < 64u;
       const uint32_t e = tab[co & 63u];
-      const int prod = mul24(val, (int)(e >> 8));          // |val| < 2^8, dequantiser < 2^15
-      my[(live && !run) ? (e & 63u) : 64u] = (int16_t)prod;  // slot 64 is a write-only dump
+      const int prod = mul24(val, (int)(e >> 8));
+      my[(live && !run) ? (e & 63u) : 64u] = (int16_t)prod;
       co += run ? (uint32_t)(sv - 63) : 1u;
     }
     if (!__any(co < 64u)) break;
@@ -297,6 +338,7 @@ __global__ __launch_bounds__(kDecThreads) void k_decode(const FrameDev* __restri
     d4 = ld(4);
   }
 
+#endif
   // ---- column pass: column c of the block is the c-th 16-byte piece of the scratch ----
   int ws[8][8];
 #pragma unroll

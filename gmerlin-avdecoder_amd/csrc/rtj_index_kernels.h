@@ -25,6 +25,12 @@
 namespace mirtj {
 
 constexpr int kSumThreads = 256;
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+#ifndef MIRTJ_SEARCH_UNROLL
+#define MIRTJ_SEARCH_UNROLL 8
+#endif
+constexpr int kSearchUnroll = MIRTJ_SEARCH_UNROLL;
 
 __global__ __launch_bounds__(kSumThreads) void k_index_summarize(const FrameDev* __restrict__ frames,
                                                                   const uint8_t* __restrict__ stream,
@@ -35,7 +41,8 @@ __global__ __launch_bounds__(kSumThreads) void k_index_summarize(const FrameDev*
   __shared__ __attribute__((aligned(16))) uint16_t s_w[kStageN];       // inclusive weight sums mod 2^16
   __shared__ __attribute__((aligned(16))) uint8_t s_nl[kTabN];         // block length if luma ...
   __shared__ __attribute__((aligned(16))) uint8_t s_nc[kTabN];         // ... or chroma
-  __shared__ uint16_t s_f[kChunk];                                     // macroblock length
+  __shared__ uint16_t s_f[kChunk];                                     // macroblock length, later 4-MB jumps
+  __shared__ uint16_t s_j[kChunk];                                     // 2-MB jumps
   __shared__ uint32_t s_wave[kSumThreads / 64];
 
   const FrameDev f = frames[blockIdx.y];
@@ -90,6 +97,63 @@ __global__ __launch_bounds__(kSumThreads) void k_index_summarize(const FrameDev*
   }
   __syncthreads();
 
+#ifndef MIRTJ_SEARCH_SCALAR
+  // ---- 3. block length at every position, for both block types ----
+  // Both searches run side by side as packed 16-bit lanes (.x luma, .y chroma): every index and
+  // every weight sum fits 16 bits, so one v_pk_* instruction serves the two block types.
+  // kSearchUnroll positions are searched together so that their LDS reads overlap: each search is
+  // a chain of six dependent reads.
+  const uint32_t lb8 = (uint32_t)lut[f.qidx].lb8, cb8 = (uint32_t)lut[f.qidx].cb8;
+  const u16x2 bt8v = {(unsigned short)lb8, (unsigned short)cb8};
+  const u16x2 needv = {(unsigned short)(63u - lb8), (unsigned short)(63u - cb8)};
+  const u16x2 onev = {1, 1};
+  for (int i0 = tid; i0 < kTabN; i0 += kSumThreads * kSearchUnroll) {
+    u16x2 lo[kSearchUnroll], hi[kSearchUnroll], tgt[kSearchUnroll];
+#pragma unroll
+    for (int u = 0; u < kSearchUnroll; u++) {
+      const int i = min(i0 + u * kSumThreads, kTabN - 1);
+      const u16x2 iv = {(unsigned short)i, (unsigned short)i};
+      const u16x2 iq = iv + bt8v;  // last non-token byte
+      const u16x2 wq = {s_w[iq.x], s_w[iq.y]};
+      tgt[u] = wq + needv;
+      lo[u] = iq + onev;  // the last token lies in [lo, hi] (weights are >= 1)
+      hi[u] = iq + needv;
+    }
+#pragma unroll
+    for (int it = 0; it < 6; it++) {
+#pragma unroll
+      for (int u = 0; u < kSearchUnroll; u++) {
+        const u16x2 mid = (lo[u] + hi[u]) >> 1;
+        const u16x2 wm = {s_w[mid.x], s_w[mid.y]};
+        // all ones in each half where W[mid] < target (the sums differ by < 2^15); kept opaque so
+        // that the two selects below stay single 32-bit bit-field inserts
+        uint32_t lt;
+        asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]"
+            : "=v"(lt)
+            : "v"(__builtin_bit_cast(uint32_t, (u16x2)(wm - tgt[u]))));
+        const uint32_t m32 = __builtin_bit_cast(uint32_t, mid),
+                       m1 = __builtin_bit_cast(uint32_t, (u16x2)(mid + onev));
+        const uint32_t h32 = __builtin_bit_cast(uint32_t, hi[u]), l32 = __builtin_bit_cast(uint32_t, lo[u]);
+        hi[u] = __builtin_bit_cast(u16x2, (h32 & lt) | (m32 & ~lt));
+        lo[u] = __builtin_bit_cast(u16x2, (m1 & lt) | (l32 & ~lt));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kSearchUnroll; u++) {
+      const int i = i0 + u * kSumThreads;
+      if (i < kTabN) {
+        const u16x2 iv = {(unsigned short)i, (unsigned short)i};
+        const u16x2 lenv = hi[u] + onev - iv;
+        uint32_t l0 = needv.x ? lenv.x : 64u, l1 = needv.y ? lenv.y : 64u;
+        if (s_b[i] == 0xFFu) l0 = l1 = 1u;
+        s_nl[i] = (uint8_t)l0;
+        s_nc[i] = (uint8_t)l1;
+      }
+    }
+  }
+  __syncthreads();
+
+#else
   // ---- 3. block length at every position, for both block types ----
   const uint32_t lb8 = (uint32_t)lut[f.qidx].lb8, cb8 = (uint32_t)lut[f.qidx].cb8;
   for (int i = tid; i < kTabN; i += kSumThreads) {
@@ -116,6 +180,7 @@ __global__ __launch_bounds__(kSumThreads) void k_index_summarize(const FrameDev*
   }
   __syncthreads();
 
+#endif
   // both lengths of the chunk's own positions go to HBM for k_index_emit: (luma | chroma << 8)
   {
     uint4* dst = (uint4*)(lentab + (size_t)(f.sum_base + c) * kChunk);
@@ -142,7 +207,43 @@ __global__ __launch_bounds__(kSumThreads) void k_index_summarize(const FrameDev*
     s_f[p] = (uint16_t)(q - p);
   }
   __syncthreads();
+#ifdef MIRTJ_WALK_DOUBLED  // measured slower on MI355X (two more LDS passes + barriers): off
+  // two rounds of pointer doubling: (bytes << 3) | macroblocks covered by a jump that takes up to
+  // four macroblocks but never starts one at or past the chunk end
+  for (int p = tid; p < kChunk; p += kSumThreads) {
+    uint32_t q = p + s_f[p], n = 1;
+    if (q < (uint32_t)kChunk) {
+      q += s_f[q];
+      n = 2;
+    }
+    s_j[p] = (uint16_t)(((q - p) << 3) | n);
+  }
+  __syncthreads();
+  for (int p = tid; p < kChunk; p += kSumThreads) {
+    const uint32_t v = s_j[p];
+    uint32_t q = p + (v >> 3), n = v & 7u;
+    if (q < (uint32_t)kChunk) {
+      const uint32_t v2 = s_j[q];
+      q += v2 >> 3;
+      n += v2 & 7u;
+    }
+    s_f[p] = (uint16_t)(((q - p) << 3) | n);  // s_f is free again: nobody reads single lengths any more
+  }
+  __syncthreads();
 
+  // ---- 5. walk every possible entry offset to the end of the chunk ----
+  uint32_t* out = summary + (size_t)(f.sum_base + c) * kEntries;
+  for (int e = tid; e < kEntries; e += kSumThreads) {
+    uint32_t p = e, cnt = 0;
+    while (p < (uint32_t)kChunk) {
+      const uint32_t v = s_f[p];
+      p += v >> 3;
+      cnt += v & 7u;
+    }
+    out[e] = (cnt << 16) | (p - (uint32_t)kChunk);
+  }
+}
+#else
   // ---- 5. walk every possible entry offset to the end of the chunk ----
   uint32_t* out = summary + (size_t)(f.sum_base + c) * kEntries;
   for (int e = tid; e < kEntries; e += kSumThreads) {
@@ -154,6 +255,7 @@ __global__ __launch_bounds__(kSumThreads) void k_index_summarize(const FrameDev*
     out[e] = (cnt << 16) | (p - (uint32_t)kChunk);
   }
 }
+#endif
 
 // One workgroup per packet.  Summaries are pulled through LDS a tile at a time; lane 0 chains them.
 constexpr int kResTile = 24;
@@ -265,7 +367,7 @@ __global__ __launch_bounds__(kEmitThreads) void k_index_emit(const FrameDev* __r
   if (tid == 0) {
     uint32_t q = q0, n = 0;
     const uint32_t want = m1 - m0;
-    while (q < (uint32_t)kChunk && n < want) {
+    while (q < (uint32_t)kChunk && n < want && n < (uint32_t)kMaxMbPerChunk) {
       s_mb[n++] = (uint16_t)q;
       q += s_f[q];
     }

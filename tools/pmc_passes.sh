@@ -1,0 +1,19 @@
+#!/bin/bash
+# Collects rocprofv3 PMC counters for bench.py in separate passes (never combined with tracing),
+# into gpurun_out/pmc/<pass>/.  Usage (on the GPU box): bash tools/pmc_passes.sh [bench args...]
+set -u
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/pmc
+mkdir -p $OUT
+ARGS="${@:---steps 3 --warmup 1 --no-cpu}"
+run() { # name counters...
+  local name=$1; shift
+  timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py $ARGS > $OUT/$name.log 2>&1
+  echo "$name rc=$?"
+}
+run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD
+run sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE
+run fetch FETCH_SIZE
+run write WRITE_SIZE
+run grbm GRBM_GUI_ACTIVE
+find $OUT -name "*counter_collection.csv" | head
