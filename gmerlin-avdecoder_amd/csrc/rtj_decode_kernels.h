@@ -199,7 +199,7 @@ constexpr int kDecThreads = 64;
 constexpr int kCoefStride = MIRTJ_COEF_STRIDE;  // int16 per lane: 64 + 8 pad (144 B, conflict-free b128 reads)
 
 // ---------------------------------------------------------------------------------------
-// k_decode: grid (3 * groups, frames), one wave per workgroup.  A group is kMbPerGroup
+// k_decode: grid (3 * groups rounded up to 8, frames), one wave per workgroup.  A group is kMbPerGroup
 // consecutive macroblocks; its three waves take
 //   part 0: the 64 upper luma blocks (Y0,Y1 of each MB), part 1: the 64 lower ones,
 //   part 2: 32 Cb + 32 Cr blocks.
@@ -218,7 +218,11 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
   __shared__ uint32_t s_tab[64];  // per zig-zag slot: (dequantiser << 8) | transposed position
 
   const FrameDev f = frames[blockIdx.y];
-  const uint32_t grp = blockIdx.x / 3u, part = blockIdx.x - 3u * grp;
+  // part-major numbering with the group count padded to a multiple of 8: the three waves of a
+  // group get linear ids that differ by a multiple of 8, i.e. (as workgroups are dealt round-robin
+  // to the 8 XCDs) they share one L2 and the group's stream bytes are fetched from HBM once
+  const uint32_t gpad = gridDim.x / 3u;
+  const uint32_t part = blockIdx.x / gpad, grp = blockIdx.x - part * gpad;
   const uint32_t mb0 = grp * kMbPerGroup;
   if (mb0 >= f.nmb) return;
   const int lane = threadIdx.x;

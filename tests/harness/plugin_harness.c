@@ -1,0 +1,133 @@
+/*
+ * plugin_harness.c — drives video_rtjpeg_mi355x.c exactly the way lib/video.c drives a
+ * bgav_video_decoder_t (bgav_video_start: lib/video.c:375-463; read_video_copy: :279-312), with
+ * the small slice of bgav/gavl it needs implemented here (registry as lib/codecs.c:201-279, packet
+ * queue behind bgav_stream_get_packet_read, frame metadata copy as lib/video.c:861-871).
+ *
+ *   plugin_harness <packets.bin> <image_w> <image_h> <out.bin> [skip_every]
+ *
+ * packets.bin: repeated { u32 le length, bytes }.  out.bin: for every decoded frame the cropped
+ * planes Y (w*h), U, V ((w+1)/2*(h+1)/2 each), tightly packed, followed by 8 bytes pts (le).
+ * Exit codes: 0 ok, 3 no decoder accepted the stream (e.g. no GPU), 4 init failed, 1 usage/io.
+ */
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <avdec_private.h>
+#include <codecs.h>
+
+/* ---- registry (lib/codecs.c:201-215, 246-279) ---- */
+static bgav_video_decoder_t *video_decoders = NULL;
+void bgav_video_decoder_register(bgav_video_decoder_t *dec) {
+  bgav_video_decoder_t **pp = &video_decoders;
+  while (*pp) pp = &(*pp)->next;
+  *pp = dec;
+  dec->next = NULL;
+}
+static bgav_video_decoder_t *find_video_decoder(uint32_t fourcc, const gavl_dictionary_t *stream) {
+  for (bgav_video_decoder_t *cur = video_decoders; cur; cur = cur->next)
+    for (int i = 0; cur->fourccs[i]; i++)
+      if (cur->fourccs[i] == fourcc && (!cur->probe || !stream || cur->probe(stream))) return cur;
+  return NULL;
+}
+
+/* ---- packet queue ---- */
+typedef struct { gavl_packet_t *pkts; int n, next; } queue_t;
+gavl_source_status_t bgav_stream_get_packet_read(bgav_stream_t *s, bgav_packet_t **p) {
+  queue_t *q = s->harness;
+  if (q->next >= q->n) return GAVL_SOURCE_EOF;
+  *p = &q->pkts[q->next++];
+  return GAVL_SOURCE_OK;
+}
+void bgav_stream_done_packet_read(bgav_stream_t *s, bgav_packet_t *p) { (void)s; (void)p; }
+void bgav_set_video_frame_from_packet(const bgav_packet_t *p, gavl_video_frame_t *f) {
+  f->timestamp = p->pts;
+  f->duration = p->duration;
+  f->timecode = p->timecode;
+  f->dst_x = p->dst_x;
+  f->dst_y = p->dst_y;
+  f->src_rect = p->src_rect;
+}
+void gavl_dictionary_set_string(gavl_dictionary_t *d, const char *key, const char *val) {
+  if (!strcmp(key, GAVL_META_FORMAT)) snprintf(d->format, sizeof d->format, "%s", val);
+}
+void gavl_log(int level, const char *domain, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  fprintf(stderr, "[%s] %s: ", level == GAVL_LOG_ERROR ? "error" : "info", domain);
+  vfprintf(stderr, fmt, ap);
+  fputc('\n', stderr);
+  va_end(ap);
+}
+
+int main(int argc, char **argv) {
+  if (argc < 5) return fprintf(stderr, "usage: %s packets.bin w h out.bin [skip_every]\n", argv[0]), 1;
+  const int iw = atoi(argv[2]), ih = atoi(argv[3]), skip_every = argc > 5 ? atoi(argv[5]) : 0;
+  FILE *fi = fopen(argv[1], "rb");
+  if (!fi) return perror(argv[1]), 1;
+  queue_t q = {0};
+  for (;;) {
+    uint32_t len;
+    if (fread(&len, 4, 1, fi) != 1) break;
+    q.pkts = realloc(q.pkts, sizeof(gavl_packet_t) * (q.n + 1));
+    gavl_packet_t *p = &q.pkts[q.n];
+    memset(p, 0, sizeof *p);
+    p->buf.buf = calloc(len + 64, 1); /* GAVL_PACKET_PADDING-style zero padding (lib/stream.c:487-492) */
+    p->buf.len = (int)len;
+    if (fread(p->buf.buf, 1, len, fi) != len) return fprintf(stderr, "short packet file\n"), 1;
+    p->pts = 1000 + 40 * (int64_t)q.n;
+    p->duration = 40;
+    q.n++;
+  }
+  fclose(fi);
+
+  /* bgav_codecs_init -> bgav_init_video_decoders_rtjpeg (lib/codecs.c:176) */
+  bgav_init_video_decoders_rtjpeg();
+
+  gavl_video_format_t fmt = {.image_width = iw, .image_height = ih};
+  gavl_dictionary_t meta = {{0}}, info = {{0}};
+  bgav_stream_t s = {0};
+  s.fourcc = BGAV_MK_FOURCC('R', 'T', 'J', '0');
+  s.m = &meta;
+  s.info = &info;
+  s.data.video.format = &fmt;
+  s.harness = &q;
+
+  /* bgav_video_start (lib/video.c:383-405) */
+  bgav_video_decoder_t *dec = find_video_decoder(s.fourcc, s.info);
+  if (!dec) return fprintf(stderr, "no video decoder accepted fourcc RTJ0\n"), 3;
+  if (!dec->init(&s)) return fprintf(stderr, "decoder init failed\n"), 4;
+  fprintf(stderr, "decoder: %s, format %s, frame %dx%d image %dx%d\n", dec->name, meta.format, fmt.frame_width,
+          fmt.frame_height, fmt.image_width, fmt.image_height);
+
+  /* the caller's frame: gavl aligns strides; use a deliberately odd pitch */
+  gavl_video_frame_t f;
+  memset(&f, 0, sizeof f);
+  const int cw = (iw + 1) / 2, ch = (ih + 1) / 2;
+  f.strides[0] = ((iw + 63) & ~63) + 64;
+  f.strides[1] = f.strides[2] = ((cw + 63) & ~63) + 64;
+  f.planes[0] = malloc((size_t)f.strides[0] * ih);
+  f.planes[1] = malloc((size_t)f.strides[1] * ch);
+  f.planes[2] = malloc((size_t)f.strides[2] * ch);
+
+  FILE *fo = fopen(argv[4], "wb");
+  if (!fo) return perror(argv[4]), 1;
+  int nframes = 0, k = 0;
+  for (;;) { /* read_video_copy (lib/video.c:279-312) */
+    const int skip = skip_every && (++k % skip_every) == 0;
+    gavl_source_status_t st = dec->decode(&s, skip ? NULL : &f);
+    if (st != GAVL_SOURCE_OK) break;
+    if (skip) continue;
+    for (int y = 0; y < ih; y++) fwrite(f.planes[0] + (size_t)y * f.strides[0], 1, iw, fo);
+    for (int pl = 1; pl < 3; pl++)
+      for (int y = 0; y < ch; y++) fwrite(f.planes[pl] + (size_t)y * f.strides[pl], 1, cw, fo);
+    fwrite(&f.timestamp, 8, 1, fo);
+    nframes++;
+  }
+  fclose(fo);
+  dec->close(&s); /* bgav_video_stop (lib/video.c:510-514) */
+  fprintf(stderr, "%d frames\n", nframes);
+  return 0;
+}
