@@ -27,7 +27,7 @@ EXPORTS = ["mi_rtj_device_count", "mi_rtj_create", "mi_rtj_destroy", "mi_rtj_las
            "mi_rtj_dev_memset", "mi_rtj_sync", "mi_rtj_plan_create", "mi_rtj_plan_destroy",
            "mi_rtj_plan_decode", "mi_rtj_plan_info", "mi_rtj_plan_profile", "mi_rtj_plan_times",
            "mi_rtj_plan_read_index", "mi_rtj_synth_frames", "mi_rtj_encode_bound", "mi_rtj_encode_frames",
-           "mi_rtj_get_tables"]
+           "mi_rtj_get_tables", "mi_rtj_yuv420_to_rgb"]
 
 
 KERNELS = ("k_index_summarize", "k_index_resolve", "k_index_emit", "k_decode")
@@ -69,6 +69,8 @@ def load():
     L.mi_rtj_encode_bound.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     L.mi_rtj_encode_bound.restype = C.c_size_t
     L.mi_rtj_encode_frames.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, u64p, u32p]
+    L.mi_rtj_yuv420_to_rgb.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp, C.c_size_t,
+                                       C.c_size_t]
     L.mi_rtj_get_tables.argtypes = [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     _LIB = L
     return L
@@ -229,6 +231,10 @@ class MiRtj:
         d = self.alloc(host.size)
         self.h2d(d, host)
         return d, np.array(offs, np.uint64), np.array(lens, np.uint32), hdrs
+
+    # -- colour stage (N2) --
+    def to_rgb(self, fmt, w, h, n, d_planes, in_stride, d_rgb, row_pitch, out_stride):
+        self._chk(self.L.mi_rtj_yuv420_to_rgb(self.h, fmt, w, h, n, d_planes, in_stride, d_rgb, row_pitch, out_stride))
 
     # -- generator side --
     def synth(self, w, h, first, n, seed=12345, amp=8, dptr=None):

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/mi_rtjpeg.h"
+#include "rtj_color_kernels.h"
 #include "rtj_common.h"
 #include "rtj_decode_kernels.h"
 #include "rtj_encode_kernels.h"
@@ -641,6 +642,30 @@ int mi_rtj_encode_frames(mi_rtj_ctx* c, int w, int h, int Q, int n, const void* 
   }
 #undef ENC_CHK
   cleanup();
+  return MI_RTJ_OK;
+}
+
+int mi_rtj_yuv420_to_rgb(mi_rtj_ctx* c, int fmt, int w, int h, int n, const void* d_planes, size_t in_frame_stride,
+                         void* d_rgb, size_t row_pitch, size_t out_frame_stride) {
+  static const int bpp[5] = {4, 4, 3, 3, 2};
+  if (!c || !d_planes || !d_rgb || fmt < 0 || fmt > 4 || w <= 0 || h <= 0 || (w & 15) || (h & 15) || n <= 0)
+    return fail(c, MI_RTJ_ERR_ARG, "mi_rtj_yuv420_to_rgb: bad argument");
+  if (row_pitch < (size_t)w * bpp[fmt] || (row_pitch & 15) || ((uintptr_t)d_rgb & 15) || (out_frame_stride & 15) ||
+      (in_frame_stride & 15) || ((uintptr_t)d_planes & 15))
+    return fail(c, MI_RTJ_ERR_ARG, "mi_rtj_yuv420_to_rgb: buffers, row pitch and frame strides must be 16-byte aligned");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int tiles = (w / 8) * (h / 2);
+  const dim3 grid((unsigned)((tiles + 255) / 256 < 2048 ? (tiles + 255) / 256 : 2048), (unsigned)n), block(256);
+  const uint8_t* in = (const uint8_t*)d_planes;
+  uint8_t* out = (uint8_t*)d_rgb;
+  switch (fmt) {
+    case kFmtRGB32: hipLaunchKernelGGL(k_yuv420_to_rgb<kFmtRGB32>, grid, block, 0, c->stream, in, in_frame_stride, out, row_pitch, out_frame_stride, w, h); break;
+    case kFmtBGR32: hipLaunchKernelGGL(k_yuv420_to_rgb<kFmtBGR32>, grid, block, 0, c->stream, in, in_frame_stride, out, row_pitch, out_frame_stride, w, h); break;
+    case kFmtRGB24: hipLaunchKernelGGL(k_yuv420_to_rgb<kFmtRGB24>, grid, block, 0, c->stream, in, in_frame_stride, out, row_pitch, out_frame_stride, w, h); break;
+    case kFmtBGR24: hipLaunchKernelGGL(k_yuv420_to_rgb<kFmtBGR24>, grid, block, 0, c->stream, in, in_frame_stride, out, row_pitch, out_frame_stride, w, h); break;
+    default:        hipLaunchKernelGGL(k_yuv420_to_rgb<kFmtRGB16>, grid, block, 0, c->stream, in, in_frame_stride, out, row_pitch, out_frame_stride, w, h); break;
+  }
+  HIPCHK(c, hipGetLastError());
   return MI_RTJ_OK;
 }
 

@@ -280,11 +280,32 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
   const uint32_t* tab = s_tab;
   uint32_t co = 0;    // next coefficient slot (zig-zag index)
   uint32_t jbase = 0; // index of the round's first byte within the block
-#ifdef MIRTJ_DECODE_HALVES  // measured slower than plain 16-byte rounds: off
+#ifndef MIRTJ_DECODE_ROUND16  // 8-slot granularity: luma blocks here are 13..24 bytes, chroma 2..5
   while (true) {
     const uint32_t wd[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
                             __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
-    // the next 16 bytes are requested before these are consumed (luma blocks average ~17 bytes)
+    bool more = true;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      if (more) {
+#pragma unroll
+        for (int t = 8 * half; t < 8 * half + 8; t++) {
+          const uint32_t j = jbase + t;
+          const uint32_t ub = (wd[t >> 2] >> (8 * (t & 3))) & 0xFFu;
+          const int sv = (int)(int8_t)ub;
+          const int val = j == 0u ? (int)ub : sv;
+          const bool run = j > bt8 && sv > 63;
+          const bool live = co < 64u;
+          const uint32_t e = tab[co & 63u];
+          const int prod = mul24(val, (int)(e >> 8));
+          my[(live && !run) ? (e & 63u) : 64u] = (int16_t)prod;
+          co += run ? (uint32_t)(sv - 63) : 1u;
+        }
+        more = __any(co < 64u);
+      }
+    }
+    if (!more) break;
+    jbase += 16u;
     g4 += 4;
     rel += 16;
     d0 = d4;
@@ -292,26 +313,6 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
     d2 = ld(2);
     d3 = ld(3);
     d4 = ld(4);
-    bool more = true;
-#pragma unroll
-    for (int half = 0; half < 2 && more; half++) {
-#pragma unroll
-      for (int t = 8 * half; t < 8 * half + 8; t++) {
-        const uint32_t j = jbase + t;
-        const uint32_t ub = (wd[t >> 2] >> (8 * (t & 3))) & 0xFFu;
-        const int sv = (int)(int8_t)ub;
-        const int val = j == 0u ? (int)ub : sv;              // DC is the only unsigned byte
-        const bool run = j > bt8 && sv > 63;                 // zero run of sv-63 slots (scratch is already 0)
-        const bool live = co < 64u;
-        const uint32_t e = tab[co & 63u];
-        const int prod = mul24(val, (int)(e >> 8));          // |val| < 2^8, dequantiser < 2^15
-        my[(live && !run) ? (e & 63u) : 64u] = (int16_t)prod;  // slot 64 is a write-only dump
-        co += run ? (uint32_t)(sv - 63) : 1u;
-      }
-      more = __any(co < 64u);
-    }
-    if (!more) break;
-    jbase += 16u;
   }
 
 #else

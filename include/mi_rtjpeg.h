@@ -115,6 +115,15 @@ size_t mi_rtj_encode_bound(int w, int h, int n, int align);
 int mi_rtj_encode_frames(mi_rtj_ctx *ctx, int w, int h, int Q, int n, const void *d_frames,
                          void *d_stream, int align, uint64_t *pkt_offset, uint32_t *pkt_len);
 
+/* ---- colour stage: RTjpeg_yuv420rgb32 / bgr32 / rgb24 / bgr24 / rgb16
+ * (lib/RTjpeg.c:3123-3475), device resident.  n frames of contiguous Y,U,V planes (in_frame_stride
+ * bytes apart) to packed pixels: rows row_pitch bytes apart (the reference takes a rows[] pointer
+ * array), frames out_frame_stride bytes apart.  Like the reference, the 32-bit formats leave the
+ * fourth byte of every pixel as it was.  Asynchronous on the instance's stream. */
+enum { MI_RTJ_RGB32 = 0, MI_RTJ_BGR32 = 1, MI_RTJ_RGB24 = 2, MI_RTJ_BGR24 = 3, MI_RTJ_RGB16 = 4 };
+int mi_rtj_yuv420_to_rgb(mi_rtj_ctx *ctx, int fmt, int w, int h, int n, const void *d_planes,
+                         size_t in_frame_stride, void *d_rgb, size_t row_pitch, size_t out_frame_stride);
+
 /* Dequantiser tables the device uses for quality Q (1..255): 64 luma + 64 chroma entries in
  * natural order and the lb8/cb8 counts — the values RTjpeg_get_tables returns
  * (lib/RTjpeg.c:2371-2378) after RTjpeg_set_quality. */

@@ -389,3 +389,34 @@ long rtjo_encode(rtjo_enc *e, const uint8_t *y, const uint8_t *u, const uint8_t 
   }
   return (long)total;
 }
+
+/* ------------------------------------------------------------------------ */
+/* colour stage: RTjpeg_yuv420rgb32 (3123), bgr32 (3192), rgb24 (3261),      */
+/* bgr24 (3326), rgb16 (3391); constants 3071-3075.  planes[1] is Cb.        */
+/* ------------------------------------------------------------------------ */
+static inline int sat8(int32_t v) { return v > 255 ? 255 : (v < 0 ? 0 : v); }
+
+void rtjo_yuv420_to_rgb(int fmt, int w, int h, const uint8_t *y, const uint8_t *u, const uint8_t *v,
+                        uint8_t *dst, size_t pitch) {
+  for (int row = 0; row < h; row++) {
+    uint8_t *o = dst + (size_t)row * pitch;
+    for (int x = 0; x < w; x++) {
+      const int32_t cb = u[(row >> 1) * (w >> 1) + (x >> 1)] - 128, cr = v[(row >> 1) * (w >> 1) + (x >> 1)] - 128;
+      const int32_t yy = (y[row * w + x] - 16) * 76284;
+      const int r = sat8((yy + cr * 76284) >> 16);
+      const int g = sat8((yy - cr * 53281 - cb * 25625) >> 16);
+      const int b = sat8((yy + cb * 132252) >> 16);
+      switch (fmt) {
+        case 0: o[4 * x] = (uint8_t)r; o[4 * x + 1] = (uint8_t)g; o[4 * x + 2] = (uint8_t)b; break;
+        case 1: o[4 * x] = (uint8_t)b; o[4 * x + 1] = (uint8_t)g; o[4 * x + 2] = (uint8_t)r; break;
+        case 2: o[3 * x] = (uint8_t)r; o[3 * x + 1] = (uint8_t)g; o[3 * x + 2] = (uint8_t)b; break;
+        case 3: o[3 * x] = (uint8_t)b; o[3 * x + 1] = (uint8_t)g; o[3 * x + 2] = (uint8_t)r; break;
+        default: {
+          const int p = (b >> 3) | ((g >> 2) << 5) | ((r >> 3) << 11);
+          o[2 * x] = (uint8_t)(p & 0xff);
+          o[2 * x + 1] = (uint8_t)(p >> 8);
+        }
+      }
+    }
+  }
+}

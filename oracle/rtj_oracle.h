@@ -72,6 +72,12 @@ int rtjo_s2b(const uint8_t *strm, size_t avail, int bt8, const int32_t *qtbl, in
 /* coefficients -> 8x8 pixels at stride `stride` (RTjpeg_idct C path, RTjpeg.c:2209-2332) */
 void rtjo_idct(const int16_t coef[64], uint8_t *dst, int stride);
 
+/* ---- colour stage: RTjpeg_yuv420rgb32/bgr32/rgb24/bgr24/rgb16 (RTjpeg.c:3123-3475) ----
+ * fmt 0..4 in that order.  dst rows are `pitch` bytes apart; the 32-bit formats leave byte 3 of every
+ * pixel untouched, as the reference does. */
+void rtjo_yuv420_to_rgb(int fmt, int w, int h, const uint8_t *y, const uint8_t *u, const uint8_t *v,
+                        uint8_t *dst, size_t pitch);
+
 #ifdef __cplusplus
 }
 #endif

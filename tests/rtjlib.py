@@ -59,6 +59,7 @@ def oracle():
         L.rtjo_encode.restype = C.c_long
         L.rtjo_s2b.argtypes = [u8p, C.c_size_t, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int16)]
         L.rtjo_idct.argtypes = [C.POINTER(C.c_int16), u8p, C.c_int]
+        L.rtjo_yuv420_to_rgb.argtypes = [C.c_int, C.c_int, C.c_int, u8p, u8p, u8p, u8p, C.c_size_t]
         _oracle = L
     return _oracle
 
@@ -77,6 +78,31 @@ def plane_sizes(w, h):
 def split_planes(buf, w, h):
     ys, cs = plane_sizes(w, h)
     return buf[:ys], buf[ys:ys + cs], buf[ys + cs:ys + 2 * cs]
+
+
+RGB_BPP = (4, 4, 3, 3, 2)
+REF_RGB_FUNCS = ("RTjpeg_yuv420rgb32", "RTjpeg_yuv420bgr32", "RTjpeg_yuv420rgb24", "RTjpeg_yuv420bgr24",
+                 "RTjpeg_yuv420rgb16")
+
+
+def oracle_to_rgb(fmt, w, h, planes, dst, pitch):
+    """dst: uint8 array of h*pitch bytes, updated in place (byte 3 of 32-bit pixels is left alone)."""
+    y, u, v = split_planes(planes, w, h)
+    oracle().rtjo_yuv420_to_rgb(fmt, w, h, _ptr(y), _ptr(u), _ptr(v), _ptr(dst), pitch)
+
+
+def reference_to_rgb(fmt, w, h, planes, dst, pitch):
+    """The reference's own RTjpeg_yuv420* helper; it takes an array of row pointers."""
+    L = reference()
+    rtj = L.RTjpeg_init()
+    cw, ch = C.c_int(w), C.c_int(h)
+    L.RTjpeg_set_size(rtj, C.byref(cw), C.byref(ch))
+    rows = (u8p * h)(*[C.cast(dst.ctypes.data + r * pitch, u8p) for r in range(h)])
+    fn = getattr(L, REF_RGB_FUNCS[fmt])
+    fn.argtypes = [C.c_void_p, C.POINTER(u8p), C.POINTER(u8p)]
+    fn.restype = None
+    fn(rtj, _planes_arg(planes, w, h), rows)
+    L.RTjpeg_close(rtj)
 
 
 class OracleDecoder:

@@ -4,8 +4,7 @@
 set -u
 cd "$(dirname "$0")/.."
 mkdir -p gmerlin-avdecoder_amd/lib/ab
-declare -A V=( [base]="" [unroll1]="-DMIRTJ_SEARCH_UNROLL=1" [unroll2]="-DMIRTJ_SEARCH_UNROLL=2" [unroll8]="-DMIRTJ_SEARCH_UNROLL=8"
-               [dec_w5]="-DMIRTJ_DEC_WAVES=5" [dec_w5_nopad]="-DMIRTJ_DEC_WAVES=5 -DMIRTJ_COEF_STRIDE=64" [dec_nopad]="-DMIRTJ_COEF_STRIDE=64" )
+declare -A V=( [base]="" [halves]="-DMIRTJ_DECODE_HALVES" )
 if [ "${1:-build}" = build ]; then
   for k in "${!V[@]}"; do
     MI_RTJ_CFLAGS="${V[$k]}" python -c "
