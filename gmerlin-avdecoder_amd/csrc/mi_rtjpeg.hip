@@ -122,6 +122,7 @@ int fill_frame(mi_rtj_ctx* c, const uint8_t* hdr, uint64_t pkt_off, uint32_t pkt
   memset(f, 0, sizeof(*f));
   f->data_off = pkt_off + MI_RTJ_HEADER_SIZE;
   f->out_off = out_off;
+  if (pkt_len >= 0x80000000u) return fail(c, MI_RTJ_ERR_ARG, "packet of %u bytes: packets are limited to 2 GiB", pkt_len);
   f->data_len = pkt_len > MI_RTJ_HEADER_SIZE ? pkt_len - MI_RTJ_HEADER_SIZE : 0;
   f->w = (uint32_t)w;
   f->h = (uint32_t)h;

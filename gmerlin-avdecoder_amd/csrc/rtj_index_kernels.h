@@ -57,16 +57,18 @@ __global__ __launch_bounds__(kSumThreads) void k_index_summarize(const FrameDev*
     const uint8_t* g = stream + f.data_off + cbase;
     const uint32_t mis = (uint32_t)((uintptr_t)g & 3u);
     const uint32_t* g4 = (const uint32_t*)(g - mis);
+    // bytes of the packet left from the chunk start on (plans keep data_len below 2^31)
+    const uint32_t left = f.data_len > cbase ? f.data_len - cbase : 0u;
     for (int j = tid; j < kStageN / 4; j += kSumThreads) {
-      // LDS dword j = stream bytes cbase+4j .. +3 = aligned global dwords j, j+1 shifted by mis
-      const long long p0 = (long long)cbase + 4ll * j - (long long)mis;  // position of g4[j]'s first byte
+      // LDS dword j = stream bytes cbase+4j .. +3 = aligned global dwords j, j+1 shifted by mis;
+      // g4[j] starts mis bytes before chunk byte 4j
+      const uint32_t b = 4u * (uint32_t)j;
       uint32_t lo = 0, hi = 0;
-      if (p0 < (long long)f.data_len) lo = g4[j];
-      if (mis && p0 + 4 < (long long)f.data_len) hi = g4[j + 1];
+      if (b < left + mis) lo = g4[j];
+      if (mis && b + 4u < left + mis) hi = g4[j + 1];
       uint32_t v = mis ? __builtin_amdgcn_alignbyte(hi, lo, mis) : lo;
-      const long long rem = (long long)f.data_len - ((long long)cbase + 4ll * j);
-      if (rem <= 0) v = 0;
-      else if (rem < 4) v &= (1u << (8 * (int)rem)) - 1u;
+      if (b >= left) v = 0;
+      else if (left - b < 4u) v &= (1u << (8u * (left - b))) - 1u;
       s_b4[j] = v;
     }
   }

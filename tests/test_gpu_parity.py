@@ -280,6 +280,47 @@ def test_chunk_boundaries_and_long_blocks(dev):
         assert first_diff(got, want) is None
 
 
+def test_fuzz_arbitrary_bytes(dev):
+    """Packets whose payload is arbitrary bytes (not produced by any encoder): every value of the
+    DC / raw / token bytes, runs that overshoot the block, 0xFF in every position, payloads far
+    shorter or longer than the picture needs.  The behaviour is fully defined (oracle header) and
+    the device must match it and must not fault."""
+    rng = np.random.default_rng(4242)
+    pkts = []
+    for trial in range(40):
+        w, h = [(16, 16), (48, 32), (160, 64), (320, 240), (16, 512)][trial % 5]
+        Q = int(rng.choice([0, 1, 2, 17, 100, 129, 200, 255]))
+        nblk = (w // 16) * (h // 16) * 6
+        n = int(rng.integers(0, nblk * 70))
+        kind = trial % 4
+        if kind == 0:
+            body = rng.integers(0, 256, n, dtype=np.uint8)
+        elif kind == 1:  # run-heavy
+            body = rng.choice(np.array([0x40, 0x7F, 0x7E, 0x00, 0xFF, 0x3F, 0x80], np.uint8), n)
+        elif kind == 2:  # mostly small coefficients, occasional anything
+            body = rng.integers(0, 8, n, dtype=np.uint8)
+            m = rng.random(n) < 0.05
+            body[m] = rng.integers(0, 256, int(m.sum()), dtype=np.uint8)
+        else:            # many skip markers
+            body = rng.choice(np.array([0xFF, 0xFF, 0x10, 0x7F], np.uint8), n)
+        total = 12 + n
+        hdr = np.array([total & 255, (total >> 8) & 255, (total >> 16) & 255, (total >> 24) & 255, 12, 0,
+                        w & 255, w >> 8, h & 255, h >> 8, Q, 0], np.uint8)
+        pkts.append(np.concatenate([hdr, body]))
+    # the plan applies the header state machine across the batch starting from the instance's
+    # state (a quality-0 header means "zero tables" only on a fresh decoder): mirror it in the oracle
+    q_before = dev.state()[2]
+    outs = batch_decode(dev, pkts, prefill=0x21, check_index=False)
+    dec = R.OracleDecoder()
+    if q_before:
+        dec.decode(R.OracleEncoder(16, 16, q_before).encode(R.synth_frame(16, 16, 0)), np.zeros(384, np.uint8))
+    for i, (p, got) in enumerate(zip(pkts, outs)):
+        w, h = int(p[6]) | (int(p[7]) << 8), int(p[8]) | (int(p[9]) << 8)
+        want = np.full(frame_bytes(w, h), 0x21, np.uint8)
+        dec.decode(p, want)
+        assert first_diff(got, want) is None, (i, first_diff(got, want))
+
+
 # --------------------------------------------------------------------------- generator side (N1)
 @pytest.mark.parametrize("w,h,amp", [(64, 48, 8), (320, 240, 64), (1920, 1088, 8)])
 def test_synth_matches_numpy_twin(dev, w, h, amp):
