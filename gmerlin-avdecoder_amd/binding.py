@@ -27,7 +27,7 @@ EXPORTS = ["mi_rtj_device_count", "mi_rtj_create", "mi_rtj_destroy", "mi_rtj_las
            "mi_rtj_dev_memset", "mi_rtj_sync", "mi_rtj_plan_create", "mi_rtj_plan_destroy",
            "mi_rtj_plan_decode", "mi_rtj_plan_info", "mi_rtj_plan_profile", "mi_rtj_plan_times",
            "mi_rtj_plan_read_index", "mi_rtj_synth_frames", "mi_rtj_encode_bound", "mi_rtj_encode_frames",
-           "mi_rtj_get_tables", "mi_rtj_yuv420_to_rgb"]
+           "mi_rtj_get_tables", "mi_rtj_yuv420_to_rgb", "mi_rtj_encode_stream"]
 
 
 KERNELS = ("k_index_summarize", "k_index_resolve", "k_index_emit", "k_decode")
@@ -71,6 +71,8 @@ def load():
     L.mi_rtj_encode_frames.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, u64p, u32p]
     L.mi_rtj_yuv420_to_rgb.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp, C.c_size_t,
                                        C.c_size_t]
+    L.mi_rtj_encode_stream.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp,
+                                       C.c_int, u64p, u32p]
     L.mi_rtj_get_tables.argtypes = [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     _LIB = L
     return L
@@ -243,11 +245,16 @@ class MiRtj:
         self._chk(self.L.mi_rtj_synth_frames(self.h, w, h, first, n, seed, amp, d))
         return d
 
-    def encode(self, w, h, Q, n, d_frames, align=64):
+    def encode(self, w, h, Q, n, d_frames, align=64, key_rate=0, lmask=0, cmask=0):
+        """Intra batch (key_rate 0) or one in-order stream with skip blocks (key_rate > 0)."""
         bound = self.L.mi_rtj_encode_bound(w, h, n, align)
         d_stream = self.alloc(bound)
         po = np.zeros(n, np.uint64)
         pl = np.zeros(n, np.uint32)
-        self._chk(self.L.mi_rtj_encode_frames(self.h, w, h, Q, n, d_frames, d_stream, align,
-                                              po.ctypes.data_as(u64p), pl.ctypes.data_as(u32p)))
+        if key_rate > 0:
+            self._chk(self.L.mi_rtj_encode_stream(self.h, w, h, Q, key_rate, lmask, cmask, n, d_frames, d_stream,
+                                                  align, po.ctypes.data_as(u64p), pl.ctypes.data_as(u32p)))
+        else:
+            self._chk(self.L.mi_rtj_encode_frames(self.h, w, h, Q, n, d_frames, d_stream, align,
+                                                  po.ctypes.data_as(u64p), pl.ctypes.data_as(u32p)))
         return d_stream, po, pl

@@ -582,20 +582,30 @@ size_t mi_rtj_encode_bound(int w, int h, int n, int align) {
   return (size_t)n * ((per + align - 1) / align * align) + align;
 }
 
-int mi_rtj_encode_frames(mi_rtj_ctx* c, int w, int h, int Q, int n, const void* d_frames, void* d_stream, int align,
-                         uint64_t* pkt_offset, uint32_t* pkt_len) {
+}  // extern "C" (reopened below)
+
+namespace {
+// shared body of the intra batch encoder and the in-order inter (skip-block) stream encoder
+int encode_impl(mi_rtj_ctx* c, int w, int h, int Q, int key_rate, int lmask, int cmask, int n, const void* d_frames,
+                void* d_stream, int align, uint64_t* pkt_offset, uint32_t* pkt_len) {
   if (!c || !d_frames || !d_stream || !pkt_offset || !pkt_len || w <= 0 || h <= 0 || (w & 15) || (h & 15) ||
       n <= 0 || align < 1 || (align & (align - 1)))
-    return fail(c, MI_RTJ_ERR_ARG, "mi_rtj_encode_frames: bad argument");
+    return fail(c, MI_RTJ_ERR_ARG, "mi_rtj_encode: bad argument");
   if (Q < 1) Q = 1;
   if (Q > 255) Q = 255;
+  // RTjpeg_set_intra's clamps (lib/RTjpeg.c:2459-2468)
+  key_rate = key_rate < 0 ? 0 : (key_rate > 255 ? 255 : key_rate);
+  lmask = lmask < 0 ? 0 : (lmask > 16 ? 16 : lmask);
+  cmask = cmask < 0 ? 0 : (cmask > 16 ? 16 : cmask);
+  const bool inter = key_rate > 0;
   HIPCHK(c, hipSetDevice(c->device));
   const uint32_t nblk = (uint32_t)(w / 16) * (h / 16) * 6;
   const size_t fsz = (size_t)w * h * 3 / 2;
-  const int chunk = 32;  // frames per pass: bounds the 64-byte-per-block scratch
+  const int chunk = inter ? 1 : 32;  // frames per pass: inter frames depend on each other, intra ones do not
   uint8_t *slots = nullptr, *lens = nullptr;
   uint32_t *offs = nullptr, *fbytes = nullptr;
   uint64_t* d_pktoff = nullptr;
+  int16_t* old = nullptr;
   int rc = MI_RTJ_OK;
   auto cleanup = [&]() {
     (void)hipStreamSynchronize(c->stream);
@@ -604,6 +614,7 @@ int mi_rtj_encode_frames(mi_rtj_ctx* c, int w, int h, int Q, int n, const void* 
     if (offs) (void)hipFree(offs);
     if (fbytes) (void)hipFree(fbytes);
     if (d_pktoff) (void)hipFree(d_pktoff);
+    if (old) (void)hipFree(old);
   };
 #define ENC_CHK(call)                                                                                         \
   do {                                                                                                        \
@@ -619,13 +630,17 @@ int mi_rtj_encode_frames(mi_rtj_ctx* c, int w, int h, int Q, int n, const void* 
   ENC_CHK(hipMalloc((void**)&offs, (size_t)chunk * nblk * 4));
   ENC_CHK(hipMalloc((void**)&fbytes, (size_t)chunk * 4));
   ENC_CHK(hipMalloc((void**)&d_pktoff, (size_t)chunk * 8));
+  if (inter) ENC_CHK(hipMalloc((void**)&old, (size_t)nblk * 64 * sizeof(int16_t)));
   std::vector<uint32_t> hb(chunk);
   uint64_t cursor = 0;
+  int key_count = 0;
   for (int f0 = 0; f0 < n; f0 += chunk) {
     const int m = n - f0 < chunk ? n - f0 : chunk;
     const size_t tot = (size_t)m * nblk;
+    // RTjpeg_compress: the previous-block store is cleared whenever key_count is 0 (lib/RTjpeg.c:3504-3505)
+    if (inter && key_count == 0) ENC_CHK(hipMemsetAsync(old, 0, (size_t)nblk * 64 * sizeof(int16_t), c->stream));
     hipLaunchKernelGGL(k_encode_blocks, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
-                       (const uint8_t*)d_frames + (size_t)f0 * fsz, w, h, m, c->d_lut + Q, slots, lens);
+                       (const uint8_t*)d_frames + (size_t)f0 * fsz, w, h, m, c->d_lut + Q, slots, lens, old, lmask, cmask);
     hipLaunchKernelGGL(k_encode_scan, dim3(m), dim3(256), 0, c->stream, lens, nblk, offs, fbytes);
     ENC_CHK(hipMemcpyAsync(hb.data(), fbytes, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
     ENC_CHK(hipStreamSynchronize(c->stream));
@@ -637,13 +652,27 @@ int mi_rtj_encode_frames(mi_rtj_ctx* c, int w, int h, int Q, int n, const void* 
     }
     ENC_CHK(hipMemcpyAsync(d_pktoff, pkt_offset + f0, (size_t)m * 8, hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(k_encode_pack, dim3((nblk + 255) / 256, m), dim3(256), 0, c->stream, slots, lens, offs,
-                       d_pktoff, fbytes, nblk, w, h, Q, (uint8_t*)d_stream);
+                       d_pktoff, fbytes, nblk, w, h, Q, inter ? key_count : 0, (uint8_t*)d_stream);
     ENC_CHK(hipGetLastError());
     ENC_CHK(hipStreamSynchronize(c->stream));
+    if (inter && ++key_count > key_rate) key_count = 0;  // lib/RTjpeg.c:3512-3514
   }
 #undef ENC_CHK
   cleanup();
   return MI_RTJ_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int mi_rtj_encode_frames(mi_rtj_ctx* c, int w, int h, int Q, int n, const void* d_frames, void* d_stream, int align,
+                         uint64_t* pkt_offset, uint32_t* pkt_len) {
+  return encode_impl(c, w, h, Q, 0, 0, 0, n, d_frames, d_stream, align, pkt_offset, pkt_len);
+}
+
+int mi_rtj_encode_stream(mi_rtj_ctx* c, int w, int h, int Q, int key_rate, int lmask, int cmask, int n,
+                         const void* d_frames, void* d_stream, int align, uint64_t* pkt_offset, uint32_t* pkt_len) {
+  return encode_impl(c, w, h, Q, key_rate, lmask, cmask, n, d_frames, d_stream, align, pkt_offset, pkt_len);
 }
 
 int mi_rtj_yuv420_to_rgb(mi_rtj_ctx* c, int fmt, int w, int h, int n, const void* d_planes, size_t in_frame_stride,

@@ -69,9 +69,13 @@ __device__ __forceinline__ void fdct8(const int (&p)[8], int (&r)[8]) {
 
 // One thread per 8x8 block: DCT + quantise + run-length pack into a private 64-byte slot.
 // blocks are numbered in stream order (6 per macroblock) across all frames of the call.
+// With `old` (inter mode, RTjpeg_mcompressYUV420 lib/RTjpeg.c:2841-2921 + RTjpeg_bcomp :2827-2838) the
+// call covers ONE frame: a block whose quantised coefficients all lie within `mask` of the stored
+// previous ones is emitted as the single byte 0xFF and the store is left alone; otherwise the store
+// takes the new block.
 __global__ void k_encode_blocks(const uint8_t* __restrict__ frames, int w, int h, int nframes,
                                 const QTab* __restrict__ qt, uint8_t* __restrict__ slots,
-                                uint8_t* __restrict__ lens) {
+                                uint8_t* __restrict__ lens, int16_t* __restrict__ old, int lmask, int cmask) {
   const uint32_t nmb = (uint32_t)(w / 16) * (h / 16), mbw = w / 16;
   const size_t total = (size_t)nframes * nmb * 6;
   const size_t gb = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -115,9 +119,24 @@ __global__ void k_encode_blocks(const uint8_t* __restrict__ frames, int w, int h
       blk[8 * kk + c] = (int16_t)(((int)d * q[8 * kk + c] + 32767) >> 16);  // RTjpeg_quant
     }
   }
+  uint8_t* out = slots + gb * 64;
+  if (old) {
+    int16_t* o = old + gb * 64;
+    const int mask = k < 4 ? lmask : cmask;
+    bool same = true;
+    for (int i = 0; i < 64; i++) {
+      const int d = (int)o[i] - (int)blk[i];
+      same = same && (d < 0 ? -d : d) <= mask;
+    }
+    if (same) {
+      out[0] = 0xFF;
+      lens[gb] = 1;
+      return;
+    }
+    for (int i = 0; i < 64; i++) o[i] = blk[i];
+  }
   // RTjpeg_b2s: DC clamped to 0..254, bt8 full-range bytes, then 7-bit values and zero runs
   const int bt8 = k < 4 ? qt->lb8 : qt->cb8;
-  uint8_t* out = slots + gb * 64;
   int n = 0, z = 1;
   int v = blk[c_zz[0]];
   out[n++] = (uint8_t)(v > 254 ? 254 : (v < 0 ? 0 : v));
@@ -178,13 +197,13 @@ __global__ __launch_bounds__(256) void k_encode_scan(const uint8_t* __restrict__
 __global__ void k_encode_pack(const uint8_t* __restrict__ slots, const uint8_t* __restrict__ lens,
                               const uint32_t* __restrict__ offs, const uint64_t* __restrict__ pkt_off,
                               const uint32_t* __restrict__ frame_bytes, uint32_t nblk, int w, int h, int Q,
-                              uint8_t* __restrict__ stream) {
+                              int key, uint8_t* __restrict__ stream) {
   const uint32_t fr = blockIdx.y;
   uint8_t* pkt = stream + pkt_off[fr];
   if (blockIdx.x == 0 && threadIdx.x < 12) {
     const uint32_t total = frame_bytes[fr] + 12u;
     const uint8_t hdr[12] = {(uint8_t)total, (uint8_t)(total >> 8), (uint8_t)(total >> 16), (uint8_t)(total >> 24),
-                             12, 0, (uint8_t)w, (uint8_t)(w >> 8), (uint8_t)h, (uint8_t)(h >> 8), (uint8_t)Q, 0};
+                             12, 0, (uint8_t)w, (uint8_t)(w >> 8), (uint8_t)h, (uint8_t)(h >> 8), (uint8_t)Q, (uint8_t)key};
     pkt[threadIdx.x] = hdr[threadIdx.x];
   }
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;

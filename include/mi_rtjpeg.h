@@ -115,6 +115,14 @@ size_t mi_rtj_encode_bound(int w, int h, int n, int align);
 int mi_rtj_encode_frames(mi_rtj_ctx *ctx, int w, int h, int Q, int n, const void *d_frames,
                          void *d_stream, int align, uint64_t *pkt_offset, uint32_t *pkt_len);
 
+/* The same for ONE stream whose frames are encoded in order with "unchanged block" detection
+ * (RTjpeg_set_intra + RTjpeg_compress with key_rate > 0, lib/RTjpeg.c:2455-2488, 2841-2921, 3500-3514):
+ * blocks within lmask/cmask of the previous coded block become the byte 0xFF.  Such packets must be
+ * decoded in order by one instance (mi_rtj_decode). */
+int mi_rtj_encode_stream(mi_rtj_ctx *ctx, int w, int h, int Q, int key_rate, int lmask, int cmask, int n,
+                         const void *d_frames, void *d_stream, int align, uint64_t *pkt_offset,
+                         uint32_t *pkt_len);
+
 /* ---- colour stage: RTjpeg_yuv420rgb32 / bgr32 / rgb24 / bgr24 / rgb16
  * (lib/RTjpeg.c:3123-3475), device resident.  n frames of contiguous Y,U,V planes (in_frame_stride
  * bytes apart) to packed pixels: rows row_pitch bytes apart (the reference takes a rows[] pointer

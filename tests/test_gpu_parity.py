@@ -348,6 +348,35 @@ def test_encoder_matches_oracle_bytes(dev, w, h, Q, amp):
     dev.free(d_st)
 
 
+@pytest.mark.parametrize("w,h,Q,key_rate,lm,cm", [(320, 240, 200, 4, 2, 2), (160, 128, 255, 255, 16, 16), (64, 48, 90, 1, 0, 0)])
+def test_stream_encoder_with_skip_blocks_matches_oracle(dev, w, h, Q, key_rate, lm, cm):
+    """mi_rtj_encode_stream == RTjpeg_compress with RTjpeg_set_intra(key_rate, lmask, cmask): same bytes,
+    same key counter in the header, and the packets decode in order to the oracle's pictures."""
+    n = 9
+    frames = [R.synth_frame(w, h, i // 3, seed=13, amp=3) for i in range(n)]  # repeats -> unchanged blocks
+    d_fr = dev.alloc(frame_bytes(w, h) * n)
+    dev.h2d(d_fr, np.concatenate(frames))
+    d_st, po, pl = dev.encode(w, h, Q, n, d_fr, align=1, key_rate=key_rate, lmask=lm, cmask=cm)
+    dev.sync()
+    enc = R.OracleEncoder(w, h, Q, key_rate, lm, cm)
+    d, od = P.MiRtj(), R.OracleDecoder()
+    got = np.zeros(frame_bytes(w, h), np.uint8)
+    want = got.copy()
+    skips = 0
+    for i in range(n):
+        pkt = dev.d2h(d_st, int(pl[i]), offset=int(po[i]))
+        ref = enc.encode(frames[i])
+        assert pkt.size == ref.size and first_diff(pkt, ref) is None, i
+        skips += int((pkt[12:] == 255).sum())
+        d.decode(pkt, got)
+        od.decode(ref, want)
+        assert first_diff(got, want) is None, i
+    assert skips > 0
+    d.close()
+    dev.free(d_fr)
+    dev.free(d_st)
+
+
 # --------------------------------------------------------------------------- benchmark sizes
 @pytest.mark.parametrize("row", [0, 1, 2, 3])
 def test_benchmark_size_digests_from_reference(dev, G, row):
