@@ -21,14 +21,6 @@ __constant__ uint8_t c_zz[64] = MIRTJ_ZZ_INIT;
 // wave64 inclusive prefix sum with DPP row shifts + row broadcasts (no LDS)
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
-#ifdef MIRTJ_SCAN_SHFL
-  const int lane = threadIdx.x & 63;
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t t = __shfl_up(x, d);
-    if (lane >= d) x += t;
-  }
-  return x;
-#else
   // within each row of 16 lanes: Hillis-Steele with row_shr 1,2,4,8 (out-of-row sources read 0)
   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);
   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);
@@ -39,7 +31,6 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
   // lane 31 into every lane of rows 2 and 3
   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);
   return x;
-#endif
 }
 
 // number of coefficient slots a stream byte covers when it is read as a token (lib/RTjpeg.c:171-182):
@@ -280,10 +271,11 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
   const uint32_t* tab = s_tab;
   uint32_t co = 0;    // next coefficient slot (zig-zag index)
   uint32_t jbase = 0; // index of the round's first byte within the block
-#ifndef MIRTJ_DECODE_ROUND16  // 8-slot granularity: luma blocks here are 13..24 bytes, chroma 2..5
   while (true) {
     const uint32_t wd[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
                             __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
+    // 16 bytes are in registers; they are consumed eight at a time so that short blocks stop early
+    // (here luma blocks are 13..24 bytes, chroma 2..5)
     bool more = true;
 #pragma unroll
     for (int half = 0; half < 2; half++) {
@@ -293,12 +285,12 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
           const uint32_t j = jbase + t;
           const uint32_t ub = (wd[t >> 2] >> (8 * (t & 3))) & 0xFFu;
           const int sv = (int)(int8_t)ub;
-          const int val = j == 0u ? (int)ub : sv;
-          const bool run = j > bt8 && sv > 63;
+          const int val = j == 0u ? (int)ub : sv;                // DC is the only unsigned byte
+          const bool run = j > bt8 && sv > 63;                   // zero run of sv-63 slots (scratch is already 0)
           const bool live = co < 64u;
           const uint32_t e = tab[co & 63u];
-          const int prod = mul24(val, (int)(e >> 8));
-          my[(live && !run) ? (e & 63u) : 64u] = (int16_t)prod;
+          const int prod = mul24(val, (int)(e >> 8));            // |val| < 2^8, dequantiser < 2^15
+          my[(live && !run) ? (e & 63u) : 64u] = (int16_t)prod;  // slot 64 is a write-only dump
           co += run ? (uint32_t)(sv - 63) : 1u;
         }
         more = __any(co < 64u);
@@ -315,35 +307,6 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
     d4 = ld(4);
   }
 
-#else
-  while (true) {
-    const uint32_t wd[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
-                            __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
-#pragma unroll
-    for (int t = 0; t < 16; t++) {
-      const uint32_t j = jbase + t;
-      const uint32_t ub = (wd[t >> 2] >> (8 * (t & 3))) & 0xFFu;
-      const int sv = (int)(int8_t)ub;
-      const int val = j == 0u ? (int)ub : sv;
-      const bool run = j > bt8 && sv > 63;
-      const bool live = co < 64u;
-      const uint32_t e = tab[co & 63u];
-      const int prod = mul24(val, (int)(e >> 8));
-      my[(live && !run) ? (e & 63u) : 64u] = (int16_t)prod;
-      co += run ? (uint32_t)(sv - 63) : 1u;
-    }
-    if (!__any(co < 64u)) break;
-    jbase += 16u;
-    g4 += 4;
-    rel += 16;
-    d0 = d4;
-    d1 = ld(1);
-    d2 = ld(2);
-    d3 = ld(3);
-    d4 = ld(4);
-  }
-
-#endif
   // ---- column pass: column c of the block is the c-th 16-byte piece of the scratch ----
   int ws[8][8];
 #pragma unroll

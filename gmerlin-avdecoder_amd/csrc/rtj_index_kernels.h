@@ -41,8 +41,7 @@ __global__ __launch_bounds__(kSumThreads) void k_index_summarize(const FrameDev*
   __shared__ __attribute__((aligned(16))) uint16_t s_w[kStageN];       // inclusive weight sums mod 2^16
   __shared__ __attribute__((aligned(16))) uint8_t s_nl[kTabN];         // block length if luma ...
   __shared__ __attribute__((aligned(16))) uint8_t s_nc[kTabN];         // ... or chroma
-  __shared__ uint16_t s_f[kChunk];                                     // macroblock length, later 4-MB jumps
-  __shared__ uint16_t s_j[kChunk];                                     // 2-MB jumps
+  __shared__ uint16_t s_f[kChunk];                                     // macroblock length
   __shared__ uint32_t s_wave[kSumThreads / 64];
 
   const FrameDev f = frames[blockIdx.y];
@@ -99,7 +98,6 @@ __global__ __launch_bounds__(kSumThreads) void k_index_summarize(const FrameDev*
   }
   __syncthreads();
 
-#ifndef MIRTJ_SEARCH_SCALAR
   // ---- 3. block length at every position, for both block types ----
   // Both searches run side by side as packed 16-bit lanes (.x luma, .y chroma): every index and
   // every weight sum fits 16 bits, so one v_pk_* instruction serves the two block types.
@@ -155,34 +153,6 @@ __global__ __launch_bounds__(kSumThreads) void k_index_summarize(const FrameDev*
   }
   __syncthreads();
 
-#else
-  // ---- 3. block length at every position, for both block types ----
-  const uint32_t lb8 = (uint32_t)lut[f.qidx].lb8, cb8 = (uint32_t)lut[f.qidx].cb8;
-  for (int i = tid; i < kTabN; i += kSumThreads) {
-    const uint32_t b0 = s_b[i];
-    uint32_t len[2];
-#pragma unroll
-    for (int t = 0; t < 2; t++) {
-      const uint32_t bt8 = t ? cb8 : lb8, need = 63u - bt8;
-      const uint32_t iq = (uint32_t)i + bt8;  // last non-token byte
-      const uint32_t tgt = (uint32_t)s_w[iq] + need;
-      uint32_t lo = iq + 1u, hi = iq + need;  // the last token lies in [lo, hi] (weights are >= 1)
-#pragma unroll
-      for (int it = 0; it < 6; it++) {
-        const uint32_t mid = (lo + hi) >> 1;
-        const bool ge = (((uint32_t)s_w[mid] - tgt) & 0x8000u) == 0u;  // sums differ by < 2^15
-        hi = ge ? mid : hi;
-        lo = ge ? lo : mid + 1u;
-      }
-      len[t] = need ? hi + 1u - (uint32_t)i : 64u;
-      if (b0 == 0xFFu) len[t] = 1u;
-    }
-    s_nl[i] = (uint8_t)len[0];
-    s_nc[i] = (uint8_t)len[1];
-  }
-  __syncthreads();
-
-#endif
   // both lengths of the chunk's own positions go to HBM for k_index_emit: (luma | chroma << 8)
   {
     uint4* dst = (uint4*)(lentab + (size_t)(f.sum_base + c) * kChunk);
@@ -209,43 +179,6 @@ __global__ __launch_bounds__(kSumThreads) void k_index_summarize(const FrameDev*
     s_f[p] = (uint16_t)(q - p);
   }
   __syncthreads();
-#ifdef MIRTJ_WALK_DOUBLED  // measured slower on MI355X (two more LDS passes + barriers): off
-  // two rounds of pointer doubling: (bytes << 3) | macroblocks covered by a jump that takes up to
-  // four macroblocks but never starts one at or past the chunk end
-  for (int p = tid; p < kChunk; p += kSumThreads) {
-    uint32_t q = p + s_f[p], n = 1;
-    if (q < (uint32_t)kChunk) {
-      q += s_f[q];
-      n = 2;
-    }
-    s_j[p] = (uint16_t)(((q - p) << 3) | n);
-  }
-  __syncthreads();
-  for (int p = tid; p < kChunk; p += kSumThreads) {
-    const uint32_t v = s_j[p];
-    uint32_t q = p + (v >> 3), n = v & 7u;
-    if (q < (uint32_t)kChunk) {
-      const uint32_t v2 = s_j[q];
-      q += v2 >> 3;
-      n += v2 & 7u;
-    }
-    s_f[p] = (uint16_t)(((q - p) << 3) | n);  // s_f is free again: nobody reads single lengths any more
-  }
-  __syncthreads();
-
-  // ---- 5. walk every possible entry offset to the end of the chunk ----
-  uint32_t* out = summary + (size_t)(f.sum_base + c) * kEntries;
-  for (int e = tid; e < kEntries; e += kSumThreads) {
-    uint32_t p = e, cnt = 0;
-    while (p < (uint32_t)kChunk) {
-      const uint32_t v = s_f[p];
-      p += v >> 3;
-      cnt += v & 7u;
-    }
-    out[e] = (cnt << 16) | (p - (uint32_t)kChunk);
-  }
-}
-#else
   // ---- 5. walk every possible entry offset to the end of the chunk ----
   uint32_t* out = summary + (size_t)(f.sum_base + c) * kEntries;
   for (int e = tid; e < kEntries; e += kSumThreads) {
@@ -257,7 +190,6 @@ __global__ __launch_bounds__(kSumThreads) void k_index_summarize(const FrameDev*
     out[e] = (cnt << 16) | (p - (uint32_t)kChunk);
   }
 }
-#endif
 
 // One workgroup per packet.  Summaries are pulled through LDS a tile at a time; lane 0 chains them.
 constexpr int kResTile = 24;
