@@ -27,7 +27,7 @@ EXPORTS = ["mi_rtj_device_count", "mi_rtj_create", "mi_rtj_destroy", "mi_rtj_las
            "mi_rtj_dev_memset", "mi_rtj_sync", "mi_rtj_plan_create", "mi_rtj_plan_destroy",
            "mi_rtj_plan_decode", "mi_rtj_plan_info", "mi_rtj_plan_profile", "mi_rtj_plan_times",
            "mi_rtj_plan_read_index", "mi_rtj_synth_frames", "mi_rtj_encode_bound", "mi_rtj_encode_frames",
-           "mi_rtj_get_tables", "mi_rtj_yuv420_to_rgb", "mi_rtj_encode_stream"]
+           "mi_rtj_get_tables", "mi_rtj_yuv420_to_rgb", "mi_rtj_encode_stream", "mi_rtj_decode_nocopy"]
 
 
 KERNELS = ("k_index_summarize", "k_index_resolve", "k_index_emit", "k_decode")
@@ -49,6 +49,7 @@ def load():
     L.mi_rtj_last_error.argtypes = [vp]
     L.mi_rtj_last_error.restype = C.c_char_p
     L.mi_rtj_decode.argtypes = [vp, u8p, C.c_size_t, C.POINTER(u8p), C.POINTER(C.c_int), C.c_int, C.c_int]
+    L.mi_rtj_decode_nocopy.argtypes = [vp, u8p, C.c_size_t, C.POINTER(u8p), C.POINTER(C.c_int)]
     L.mi_rtj_get_state.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mi_rtj_dev_alloc.argtypes = [vp, C.c_size_t]
     L.mi_rtj_dev_alloc.restype = vp
@@ -171,6 +172,17 @@ class MiRtj:
         planes = (u8p * 3)(C.cast(base, u8p), C.cast(base + ysz, u8p), C.cast(base + ysz + csz, u8p))
         st = (C.c_int * 3)(*strides)
         self._chk(self.L.mi_rtj_decode(self.h, pp, pkt.size, planes, st, cw, ch))
+
+    def decode_nocopy(self, pkt):
+        """Returns (y, u, v) numpy views of the instance's pinned picture, valid until the next decode."""
+        pkt = np.ascontiguousarray(pkt, dtype=np.uint8)
+        planes = (u8p * 3)()
+        st = (C.c_int * 3)()
+        self._chk(self.L.mi_rtj_decode_nocopy(self.h, pkt.ctypes.data_as(u8p), pkt.size, planes, st))
+        w = int(pkt[6]) | (int(pkt[7]) << 8)
+        h = int(pkt[8]) | (int(pkt[9]) << 8)
+        mk = lambda p, n: np.ctypeslib.as_array(p, shape=(n,))
+        return mk(planes[0], w * h), mk(planes[1], w * h // 4), mk(planes[2], w * h // 4)
 
     def state(self):
         w, h, q = C.c_int(), C.c_int(), C.c_int()

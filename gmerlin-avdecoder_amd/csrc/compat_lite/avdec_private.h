@@ -58,6 +58,7 @@ typedef struct bgav_video_decoder_s bgav_video_decoder_t;
 
 struct bgav_stream_s {
   void *decoder_priv;
+  gavl_video_frame_t *vframe; /* set by a decoder that owns its output frame: nocopy mode (lib/video.c:420-429) */
   uint32_t fourcc;
   gavl_dictionary_t *m;    /* stream metadata */
   gavl_dictionary_t *info; /* what .probe receives */
@@ -87,6 +88,9 @@ void bgav_stream_done_packet_read(bgav_stream_t *s, bgav_packet_t *p);
 void bgav_set_video_frame_from_packet(const bgav_packet_t *p, gavl_video_frame_t *f);
 void bgav_video_decoder_register(bgav_video_decoder_t *dec);
 void gavl_dictionary_set_string(gavl_dictionary_t *d, const char *key, const char *val);
+gavl_video_frame_t *gavl_video_frame_create(const gavl_video_format_t *format); /* NULL: no plane memory */
+void gavl_video_frame_null(gavl_video_frame_t *f);
+void gavl_video_frame_destroy(gavl_video_frame_t *f);
 void gavl_log(int level, const char *domain, const char *fmt, ...);
 
 #endif

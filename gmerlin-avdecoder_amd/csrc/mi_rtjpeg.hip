@@ -46,6 +46,8 @@ struct mi_rtj_ctx {
   size_t frame_bytes = 0;
   uint8_t* d_pkt = nullptr;
   size_t pkt_cap = 0;
+  uint8_t* h_frame = nullptr;     // pinned host picture of the nocopy path
+  size_t h_frame_cap = 0;
   mi_rtj_plan* single = nullptr;  // reusable 1-frame plan
 };
 
@@ -294,6 +296,7 @@ void mi_rtj_destroy(mi_rtj_ctx* c) {
   if (c->single) mi_rtj_plan_destroy(c->single);
   if (c->d_frame) (void)hipFree(c->d_frame);
   if (c->d_pkt) (void)hipFree(c->d_pkt);
+  if (c->h_frame) (void)hipHostFree(c->h_frame);
   if (c->d_lut) (void)hipFree(c->d_lut);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -489,12 +492,15 @@ int mi_rtj_plan_read_index(mi_rtj_plan* p, uint32_t* dst, size_t max_entries) {
   return MI_RTJ_OK;
 }
 
-int mi_rtj_decode(mi_rtj_ctx* c, const uint8_t* pkt, size_t len, uint8_t* const dst[3], const int dst_stride[3],
-                  int crop_w, int crop_h) {
+}  // extern "C" (reopened below)
+
+namespace {
+// Shared front half of the one-packet paths: header, (re)allocation, upload, the four kernels.
+// On return the picture is being produced on c->stream into c->d_frame.
+int decode_one_launch(mi_rtj_ctx* c, const uint8_t* pkt, size_t len) {
   if (!c || !pkt) return fail(c, MI_RTJ_ERR_ARG, "mi_rtj_decode: NULL argument");
   if (len < MI_RTJ_HEADER_SIZE) return fail(c, MI_RTJ_ERR_ARG, "mi_rtj_decode: packet shorter than its %d-byte header", MI_RTJ_HEADER_SIZE);
   HIPCHK(c, hipSetDevice(c->device));
-  // plan of one frame, rebuilt per packet (its header may change size or quality)
   if (!c->single) {
     c->single = new mi_rtj_plan();
     c->single->ctx = c;
@@ -546,11 +552,21 @@ int mi_rtj_decode(mi_rtj_ctx* c, const uint8_t* pkt, size_t len, uint8_t* const 
     const char* em = getenv("MI_RTJ_EMIT");
     p->emit_walk = em && strcmp(em, "walk") == 0;
   }
+  // pageable source: the runtime stages it; a private pinned staging copy measured no faster
   HIPCHK(c, hipMemcpyAsync(c->d_pkt, pkt, len, hipMemcpyHostToDevice, c->stream));
   int r = plan_upload(p);
   if (r != MI_RTJ_OK) return r;
-  r = plan_launch(p, c->d_pkt, c->d_frame);
+  return plan_launch(p, c->d_pkt, c->d_frame);
+}
+}  // namespace
+
+extern "C" {
+
+int mi_rtj_decode(mi_rtj_ctx* c, const uint8_t* pkt, size_t len, uint8_t* const dst[3], const int dst_stride[3],
+                  int crop_w, int crop_h) {
+  const int r = decode_one_launch(c, pkt, len);
   if (r != MI_RTJ_OK) return r;
+  const FrameDev& f = c->single->h_frames[0];
   if (dst) {
     // gavl_video_frame_copy(format, f, priv->frame) (lib/video_rtjpeg.c:82): image_width x
     // image_height region, each side's own strides — done by the copy engine on the way out.
@@ -564,6 +580,28 @@ int mi_rtj_decode(mi_rtj_ctx* c, const uint8_t* pkt, size_t len, uint8_t* const 
     HIPCHK(c, hipMemcpy2DAsync(dst[2], (size_t)dst_stride[2], c->d_frame + ysz + ysz / 4, f.w / 2, (size_t)cw, (size_t)ch, hipMemcpyDeviceToHost, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return MI_RTJ_OK;
+}
+
+int mi_rtj_decode_nocopy(mi_rtj_ctx* c, const uint8_t* pkt, size_t len, const uint8_t* planes[3], int strides[3]) {
+  if (!planes || !strides) return fail(c, MI_RTJ_ERR_ARG, "mi_rtj_decode_nocopy: NULL argument");
+  const int r = decode_one_launch(c, pkt, len);
+  if (r != MI_RTJ_OK) return r;
+  const FrameDev& f = c->single->h_frames[0];
+  const size_t ysz = (size_t)f.w * f.h, fsz = ysz * 3 / 2;
+  if (fsz > c->h_frame_cap) {
+    if (c->h_frame) (void)hipHostFree(c->h_frame);
+    c->h_frame = nullptr;
+    HIPCHK(c, hipHostMalloc((void**)&c->h_frame, fsz, hipHostMallocDefault));
+    c->h_frame_cap = fsz;
+  }
+  HIPCHK(c, hipMemcpyAsync(c->h_frame, c->d_frame, fsz, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  planes[0] = c->h_frame;
+  planes[1] = c->h_frame + ysz;
+  planes[2] = c->h_frame + ysz + ysz / 4;
+  strides[0] = (int)f.w;
+  strides[1] = strides[2] = (int)f.w / 2;
   return MI_RTJ_OK;
 }
 

@@ -26,6 +26,9 @@
 
 typedef struct {
   mi_rtj_ctx *ctx; /* owns the persistent device picture: the role of priv->frame + priv->rtjpeg */
+#ifdef MI_RTJ_NOCOPY
+  gavl_video_frame_t *vframe; /* plane pointers into the instance's pinned host picture */
+#endif
 } rtjpeg_hip_priv_t;
 
 /* .probe (include/avdec_private.h:95): claim the stream only if a gfx950 device is usable, so
@@ -52,6 +55,13 @@ static int init_rtjpeg_hip(bgav_stream_t *s) {
   s->data.video.format->frame_height = PADD(s->data.video.format->image_height);
   s->data.video.format->pixelformat = GAVL_YUV_420_P;
   gavl_dictionary_set_string(s->m, GAVL_META_FORMAT, "RTjpeg");
+#ifdef MI_RTJ_NOCOPY
+  /* nocopy mode (lib/video.c:420-429, as lib/video_yuv.c:211 does): the decoder owns the frame, the
+   * library hands s->vframe to the application and never copies it — the picture goes from the GPU
+   * straight into pinned host memory and stays there until the next packet. */
+  priv->vframe = gavl_video_frame_create(NULL);
+  s->vframe = priv->vframe;
+#endif
   return 1;
 }
 
@@ -64,6 +74,28 @@ static gavl_source_status_t decode_rtjpeg_hip(bgav_stream_t *s, gavl_video_frame
   /* We assume one frame per packet (lib/video_rtjpeg.c:69-72) */
   if ((st = bgav_stream_get_packet_read(s, &p)) != GAVL_SOURCE_OK) return st;
 
+#ifdef MI_RTJ_NOCOPY
+  /* always called with f == NULL in this mode (lib/video.c:262); picture, timestamp and duration
+   * are read back from s->vframe (lib/video.c:270-274) */
+  {
+    const uint8_t *planes[3];
+    int strides[3], i;
+    (void)f;
+    rc = mi_rtj_decode_nocopy(priv->ctx, p->buf.buf, (size_t)p->buf.len, planes, strides);
+    if (rc != MI_RTJ_OK) {
+      gavl_log(GAVL_LOG_ERROR, LOG_DOMAIN, "Decoding failed: %s", mi_rtj_last_error(priv->ctx));
+      bgav_stream_done_packet_read(s, p);
+      return GAVL_SOURCE_EOF;
+    }
+    for (i = 0; i < 3; i++) {
+      priv->vframe->planes[i] = (uint8_t *)planes[i];
+      priv->vframe->strides[i] = strides[i];
+    }
+    bgav_set_video_frame_from_packet(p, priv->vframe);
+    bgav_stream_done_packet_read(s, p);
+    return GAVL_SOURCE_OK;
+  }
+#else
   /* Skip frame: the packet is consumed, nothing is decoded (lib/video_rtjpeg.c:75-79) */
   if (!f) {
     bgav_stream_done_packet_read(s, p);
@@ -82,11 +114,17 @@ static gavl_source_status_t decode_rtjpeg_hip(bgav_stream_t *s, gavl_video_frame
   bgav_set_video_frame_from_packet(p, f);
   bgav_stream_done_packet_read(s, p);
   return GAVL_SOURCE_OK;
+#endif
 }
 
 static void close_rtjpeg_hip(bgav_stream_t *s) {
   rtjpeg_hip_priv_t *priv = s->decoder_priv;
   if (!priv) return;
+#ifdef MI_RTJ_NOCOPY
+  gavl_video_frame_null(priv->vframe); /* the planes belong to the instance, not to gavl */
+  gavl_video_frame_destroy(priv->vframe);
+  s->vframe = NULL;
+#endif
   mi_rtj_destroy(priv->ctx);
   free(priv);
   s->decoder_priv = NULL;

@@ -59,6 +59,12 @@ const char *mi_rtj_last_error(const mi_rtj_ctx *ctx);
  * dst == NULL decodes into the persistent frame only.  Returns MI_RTJ_OK or an error. */
 int mi_rtj_decode(mi_rtj_ctx *ctx, const uint8_t *pkt, size_t len, uint8_t *const dst[3],
                   const int dst_stride[3], int crop_w, int crop_h);
+/* The same decode for a decoder that owns its output frame (the reference's "nocopy" mode: the
+ * decoder sets s->vframe in init and decode(s, NULL) leaves the picture there, lib/video.c:253-277,
+ * 420-429).  The whole coded picture lands in pinned host memory owned by the instance; planes[]/
+ * strides[] describe it (stride = coded width) and stay valid until the next decode call. */
+int mi_rtj_decode_nocopy(mi_rtj_ctx *ctx, const uint8_t *pkt, size_t len, const uint8_t *planes[3],
+                         int strides[3]);
 /* Geometry and effective quality the last mi_rtj_decode / plan used (RTjpeg_t width/height/Q). */
 void mi_rtj_get_state(const mi_rtj_ctx *ctx, int *width, int *height, int *quality);
 

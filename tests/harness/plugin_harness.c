@@ -53,6 +53,12 @@ void bgav_set_video_frame_from_packet(const bgav_packet_t *p, gavl_video_frame_t
 void gavl_dictionary_set_string(gavl_dictionary_t *d, const char *key, const char *val) {
   if (!strcmp(key, GAVL_META_FORMAT)) snprintf(d->format, sizeof d->format, "%s", val);
 }
+gavl_video_frame_t *gavl_video_frame_create(const gavl_video_format_t *format) {
+  (void)format; /* only the NULL-format form (no plane memory) is needed here */
+  return calloc(1, sizeof(gavl_video_frame_t));
+}
+void gavl_video_frame_null(gavl_video_frame_t *f) { memset(f->planes, 0, sizeof f->planes); }
+void gavl_video_frame_destroy(gavl_video_frame_t *f) { free(f); }
 void gavl_log(int level, const char *domain, const char *fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -115,15 +121,21 @@ int main(int argc, char **argv) {
   FILE *fo = fopen(argv[4], "wb");
   if (!fo) return perror(argv[4]), 1;
   int nframes = 0, k = 0;
-  for (;;) { /* read_video_copy (lib/video.c:279-312) */
-    const int skip = skip_every && (++k % skip_every) == 0;
-    gavl_source_status_t st = dec->decode(&s, skip ? NULL : &f);
-    if (st != GAVL_SOURCE_OK) break;
-    if (skip) continue;
-    for (int y = 0; y < ih; y++) fwrite(f.planes[0] + (size_t)y * f.strides[0], 1, iw, fo);
+  for (;;) {
+    const gavl_video_frame_t *res;
+    if (s.vframe) { /* read_video_nocopy (lib/video.c:253-277): decode(s, NULL), picture in s->vframe */
+      if (dec->decode(&s, NULL) != GAVL_SOURCE_OK) break;
+      res = s.vframe;
+    } else {        /* read_video_copy (lib/video.c:279-312) */
+      const int skip = skip_every && (++k % skip_every) == 0;
+      if (dec->decode(&s, skip ? NULL : &f) != GAVL_SOURCE_OK) break;
+      if (skip) continue;
+      res = &f;
+    }
+    for (int y = 0; y < ih; y++) fwrite(res->planes[0] + (size_t)y * res->strides[0], 1, iw, fo);
     for (int pl = 1; pl < 3; pl++)
-      for (int y = 0; y < ch; y++) fwrite(f.planes[pl] + (size_t)y * f.strides[pl], 1, cw, fo);
-    fwrite(&f.timestamp, 8, 1, fo);
+      for (int y = 0; y < ch; y++) fwrite(res->planes[pl] + (size_t)y * res->strides[pl], 1, cw, fo);
+    fwrite(&res->timestamp, 8, 1, fo);
     nframes++;
   }
   fclose(fo);

@@ -198,6 +198,19 @@ def test_bad_geometry_and_arguments(dev):
         dev.decode(pkt[:5], None)
 
 
+def test_nocopy_path_returns_the_whole_coded_picture(dev):
+    w, h = 320, 240
+    enc = R.OracleEncoder(w, h, 230, key_rate=3, lmask=2, cmask=2)
+    d, od = P.MiRtj(), R.OracleDecoder()
+    want = np.zeros(frame_bytes(w, h), np.uint8)
+    for i in range(5):
+        pkt = enc.encode(R.synth_frame(w, h, i // 2, seed=2, amp=3))
+        y, u, v = d.decode_nocopy(pkt)
+        od.decode(pkt, want)
+        assert first_diff(np.concatenate([y, u, v]), want) is None, i
+    d.close()
+
+
 def test_crop_and_strides_like_gavl_frame_copy(dev):
     """1080p is coded as 1920x1088 and handed back as the 1920x1080 crop with the caller's strides
     (lib/video_rtjpeg.c:50-51,82)."""

@@ -12,7 +12,7 @@ import pytest
 import rtjlib as R
 from pkg import ROOT
 
-HARNESS = os.path.join(ROOT, "gmerlin-avdecoder_amd", "lib", "plugin_harness")
+HARNESS = HARNESS_COPY = os.path.join(ROOT, "gmerlin-avdecoder_amd", "lib", "plugin_harness")
 
 
 def build_harness():
@@ -66,10 +66,12 @@ def expected_stream(pkts, w, h, iw, ih, skip_every):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("w,h,iw,ih,key_rate,skip_every", [(320, 240, 320, 240, 0, 0), (320, 240, 314, 234, 4, 0),
-                                                           (1920, 1088, 1920, 1080, 0, 0), (160, 128, 160, 121, 3, 3)])
-def test_wrapper_decodes_like_the_reference_wrapper(tmp_path, w, h, iw, ih, key_rate, skip_every):
+@pytest.mark.parametrize("w,h,iw,ih,key_rate,skip_every,nocopy",
+                         [(320, 240, 320, 240, 0, 0, 0), (320, 240, 314, 234, 4, 0, 0), (1920, 1088, 1920, 1080, 0, 0, 0),
+                          (160, 128, 160, 121, 3, 3, 0), (320, 240, 314, 234, 4, 0, 1), (1920, 1088, 1920, 1080, 0, 0, 1)])
+def test_wrapper_decodes_like_the_reference_wrapper(tmp_path, w, h, iw, ih, key_rate, skip_every, nocopy):
     build_harness()
+    HARNESS = HARNESS_COPY + ("_nocopy" if nocopy else "")
     enc = R.OracleEncoder(w, h, 220, key_rate, 2, 2)
     n = 3 if w >= 1920 else 7
     pkts = [enc.encode(R.synth_frame(w, h, i // 2, seed=21, amp=4)) for i in range(n)]
