@@ -2,6 +2,7 @@
 gfx950 device, construction raises MiRtjError with the library's own message."""
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -96,11 +97,13 @@ def get_tables(Q):
 class Plan:
     def __init__(self, owner, handle, n):
         self.owner, self.h, self.n = owner, handle, n
+        owner._plans.add(self)
 
     def close(self):
         if self.h:
             self.owner.L.mi_rtj_plan_destroy(self.h)
             self.h = None
+            self.owner._plans.discard(self)
 
     def __del__(self):
         self.close()
@@ -135,12 +138,15 @@ class MiRtj:
 
     def __init__(self, device=-1):
         self.L = load()
+        self._plans = weakref.WeakSet()
         self.h = self.L.mi_rtj_create(device)
         if not self.h:
             raise MiRtjError("mi_rtj_create failed: " + self.L.mi_rtj_last_error(None).decode())
 
     def close(self):
         if getattr(self, "h", None):
+            for p in list(self._plans):  # a plan must not outlive its instance
+                p.close()
             self.L.mi_rtj_destroy(self.h)
             self.h = None
 

@@ -252,7 +252,10 @@ __global__ __launch_bounds__(64) void k_index_emit_walk(const FrameDev* __restri
 // k_index_emit: per chunk, from the block lengths k_index_summarize left in HBM and the true
 // entry k_index_resolve found: macroblock lengths in parallel, one short serial walk over the
 // chunk's macroblocks, then the six block offsets of every macroblock in parallel.
-constexpr int kEmitThreads = 256;
+#ifndef MIRTJ_EMIT_THREADS
+#define MIRTJ_EMIT_THREADS 256
+#endif
+constexpr int kEmitThreads = MIRTJ_EMIT_THREADS;
 constexpr int kMaxMbPerChunk = kChunk / 6 + 2;  // a macroblock is at least six 1-byte blocks
 __global__ __launch_bounds__(kEmitThreads) void k_index_emit(const FrameDev* __restrict__ frames,
                                                               const uint16_t* __restrict__ lentab,
@@ -260,48 +263,64 @@ __global__ __launch_bounds__(kEmitThreads) void k_index_emit(const FrameDev* __r
                                                               const uint32_t* __restrict__ chunk_mb,
                                                               uint32_t* __restrict__ blkoff) {
   __shared__ __attribute__((aligned(16))) uint16_t s_len[kTabN + 8];  // (luma | chroma << 8) per position
-  __shared__ uint16_t s_f[kChunk];
-  __shared__ uint16_t s_mb[kMaxMbPerChunk];
+  __shared__ uint16_t s_f[kChunk];   // macroblock length
+  __shared__ uint16_t s_mb[kMaxMbPerChunk + 2];
   __shared__ uint32_t s_cnt[2];
 
   const FrameDev f = frames[blockIdx.y];
   const uint32_t c = blockIdx.x;
   if (c >= f.nchunks) return;
-  const uint32_t m0 = chunk_mb[f.chunk_base + c];
-  const uint32_t m1 = chunk_mb[f.chunk_base + c + 1];  // == nmb for the last chunk
-  if (m0 >= m1) return;
   const int tid = threadIdx.x;
   const uint32_t cbase = c * (uint32_t)kChunk;
-  const uint32_t q0 = chunk_pos[f.chunk_base + c] - cbase;  // entry offset, < kEntries
-  uint32_t* out = blkoff + f.blk_base;
 
   // ---- block lengths of [cbase, cbase + kTabN); past the packet's last chunk every byte is 0,
-  //      and a block of zero bytes is 64 bytes long whatever its type ----
+  //      and a block of zero bytes is 64 bytes long whatever its type.  The kernel is bound by the
+  //      latency of its dependent steps, so this load is issued before anything else ----
+  constexpr int kPieces = (kTabN + 7) / 8, kPer = (kPieces + kEmitThreads - 1) / kEmitThreads;
+  uint4 lens[kPer];
   {
     const size_t have = (size_t)(f.nchunks - c) * kChunk;  // table entries from cbase to the end of the packet
     const uint4* src = (const uint4*)(lentab + (size_t)(f.sum_base + c) * kChunk);
-    for (int i = tid; i < (kTabN + 7) / 8; i += kEmitThreads) {
-      uint4 v = make_uint4(0x40404040u, 0x40404040u, 0x40404040u, 0x40404040u);
-      if ((size_t)i * 8 + 8 <= have) v = src[i];  // kChunk is a multiple of 8, so no piece straddles the end
-      ((uint4*)s_len)[i] = v;
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+      const int i = tid + k * kEmitThreads;
+      lens[k] = make_uint4(0x40404040u, 0x40404040u, 0x40404040u, 0x40404040u);
+      if (i < kPieces && (size_t)i * 8 + 8 <= have) lens[k] = src[i];  // kChunk % 8 == 0: no piece straddles the end
     }
   }
+  const uint32_t m0 = chunk_mb[f.chunk_base + c];
+  const uint32_t m1 = chunk_mb[f.chunk_base + c + 1];  // == nmb for the last chunk
+  if (m0 >= m1) return;
+  const uint32_t q0 = chunk_pos[f.chunk_base + c] - cbase;  // entry offset, < kEntries
+  uint32_t* out = blkoff + f.blk_base;
+#pragma unroll
+  for (int k = 0; k < kPer; k++) {
+    const int i = tid + k * kEmitThreads;
+    if (i < kPieces) ((uint4*)s_len)[i] = lens[k];
+  }
   __syncthreads();
-  for (int p = tid; p < kChunk; p += kEmitThreads) {
-    uint32_t q = p;
-    q += s_len[q] & 0xFFu;
-    q += s_len[q] & 0xFFu;
-    q += s_len[q] & 0xFFu;
-    q += s_len[q] & 0xFFu;
-    q += s_len[q] >> 8;
-    q += s_len[q] >> 8;
-    s_f[p] = (uint16_t)(q - p);
+
+  // ---- macroblock length at every position: six dependent reads, four positions chased together ----
+  for (int p0 = tid; p0 < kChunk; p0 += 4 * kEmitThreads) {
+    uint32_t q[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) q[u] = min(p0 + u * kEmitThreads, kChunk - 1);
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) q[u] += k < 4 ? (s_len[q[u]] & 0xFFu) : (s_len[q[u]] >> 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int p = p0 + u * kEmitThreads;
+      if (p < kChunk) s_f[p] = (uint16_t)(q[u] - p);
+    }
   }
   __syncthreads();
   if (tid == 0) {
     uint32_t q = q0, n = 0;
-    const uint32_t want = m1 - m0;
-    while (q < (uint32_t)kChunk && n < want && n < (uint32_t)kMaxMbPerChunk) {
+    const uint32_t want = min(m1 - m0, (uint32_t)kMaxMbPerChunk);
+    while (q < (uint32_t)kChunk && n < want) {
       s_mb[n++] = (uint16_t)q;
       q += s_f[q];
     }
