@@ -25,8 +25,6 @@
 namespace mirtj {
 
 constexpr int kSumThreads = 256;
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-typedef short s16x2 __attribute__((ext_vector_type(2)));
 #ifndef MIRTJ_SEARCH_UNROLL
 #define MIRTJ_SEARCH_UNROLL 8
 #endif
@@ -99,55 +97,50 @@ __global__ __launch_bounds__(kSumThreads) void k_index_summarize(const FrameDev*
   __syncthreads();
 
   // ---- 3. block length at every position, for both block types ----
-  // Both searches run side by side as packed 16-bit lanes (.x luma, .y chroma): every index and
-  // every weight sum fits 16 bits, so one v_pk_* instruction serves the two block types.
-  // kSearchUnroll positions are searched together so that their LDS reads overlap: each search is
-  // a chain of six dependent reads.
+  // A block that starts at i has its last raw byte at iq = i + bt8 and ends at iq + d, d the
+  // smallest distance with W[iq + d] >= W[iq] + need.  d - 1 is built bit by bit (32, 16, .. 1): the
+  // probe distance is an immediate offset of the LDS read, so a step is three vector instructions
+  // (subtract, extract the "still below" bit, shift-add it into the byte address).  Searching the
+  // full 1..64 window is exact for any need <= 63 because the predicate is monotone.
+  // kSearchUnroll positions x 2 types are searched together so that their dependent reads overlap.
   const uint32_t lb8 = (uint32_t)lut[f.qidx].lb8, cb8 = (uint32_t)lut[f.qidx].cb8;
-  const u16x2 bt8v = {(unsigned short)lb8, (unsigned short)cb8};
-  const u16x2 needv = {(unsigned short)(63u - lb8), (unsigned short)(63u - cb8)};
-  const u16x2 onev = {1, 1};
+  const uint32_t bt8v[2] = {lb8, cb8}, needv[2] = {63u - lb8, 63u - cb8};
   for (int i0 = tid; i0 < kTabN; i0 += kSumThreads * kSearchUnroll) {
-    u16x2 lo[kSearchUnroll], hi[kSearchUnroll], tgt[kSearchUnroll];
+    uint32_t addr[kSearchUnroll][2], tgt[kSearchUnroll][2];
 #pragma unroll
     for (int u = 0; u < kSearchUnroll; u++) {
-      const int i = min(i0 + u * kSumThreads, kTabN - 1);
-      const u16x2 iv = {(unsigned short)i, (unsigned short)i};
-      const u16x2 iq = iv + bt8v;  // last non-token byte
-      const u16x2 wq = {s_w[iq.x], s_w[iq.y]};
-      tgt[u] = wq + needv;
-      lo[u] = iq + onev;  // the last token lies in [lo, hi] (weights are >= 1)
-      hi[u] = iq + needv;
+      const uint32_t i = (uint32_t)min(i0 + u * kSumThreads, kTabN - 1);
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        addr[u][t] = 2u * (i + bt8v[t]);  // byte address of W[iq]
+        tgt[u][t] = (uint32_t)s_w[i + bt8v[t]] + needv[t];
+      }
     }
 #pragma unroll
-    for (int it = 0; it < 6; it++) {
+    for (int step = 32; step >= 1; step >>= 1) {
 #pragma unroll
       for (int u = 0; u < kSearchUnroll; u++) {
-        const u16x2 mid = (lo[u] + hi[u]) >> 1;
-        const u16x2 wm = {s_w[mid.x], s_w[mid.y]};
-        // all ones in each half where W[mid] < target (the sums differ by < 2^15); kept opaque so
-        // that the two selects below stay single 32-bit bit-field inserts
-        uint32_t lt;
-        asm("v_pk_ashrrev_i16 %0, 15, %1 op_sel_hi:[0,1]"
-            : "=v"(lt)
-            : "v"(__builtin_bit_cast(uint32_t, (u16x2)(wm - tgt[u]))));
-        const uint32_t m32 = __builtin_bit_cast(uint32_t, mid),
-                       m1 = __builtin_bit_cast(uint32_t, (u16x2)(mid + onev));
-        const uint32_t h32 = __builtin_bit_cast(uint32_t, hi[u]), l32 = __builtin_bit_cast(uint32_t, lo[u]);
-        hi[u] = __builtin_bit_cast(u16x2, (h32 & lt) | (m32 & ~lt));
-        lo[u] = __builtin_bit_cast(u16x2, (m1 & lt) | (l32 & ~lt));
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          const uint32_t w = *(const uint16_t*)((const uint8_t*)s_w + addr[u][t] + 2 * step);
+          const uint32_t below = ((w - tgt[u][t]) >> 15) & 1u;  // sums differ by < 2^15, compared mod 2^16
+          addr[u][t] += below * (2u * (uint32_t)step);
+        }
       }
     }
 #pragma unroll
     for (int u = 0; u < kSearchUnroll; u++) {
       const int i = i0 + u * kSumThreads;
       if (i < kTabN) {
-        const u16x2 iv = {(unsigned short)i, (unsigned short)i};
-        const u16x2 lenv = hi[u] + onev - iv;
-        uint32_t l0 = needv.x ? lenv.x : 64u, l1 = needv.y ? lenv.y : 64u;
-        if (s_b[i] == 0xFFu) l0 = l1 = 1u;
-        s_nl[i] = (uint8_t)l0;
-        s_nc[i] = (uint8_t)l1;
+        uint32_t len[2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          const uint32_t e = addr[u][t] / 2u + 1u;  // index of the block's last byte
+          len[t] = needv[t] ? e + 1u - (uint32_t)i : 64u;
+        }
+        if (s_b[i] == 0xFFu) len[0] = len[1] = 1u;
+        s_nl[i] = (uint8_t)len[0];
+        s_nc[i] = (uint8_t)len[1];
       }
     }
   }
