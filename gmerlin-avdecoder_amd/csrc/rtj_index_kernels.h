@@ -30,7 +30,7 @@ constexpr int kSumThreads = 256;
 #endif
 constexpr int kSearchUnroll = MIRTJ_SEARCH_UNROLL;
 
-__global__ __launch_bounds__(kSumThreads) void k_index_summarize(const FrameDev* __restrict__ frames,
+__global__ __launch_bounds__(kSumThreads, 5) void k_index_summarize(const FrameDev* __restrict__ frames,
                                                                   const uint8_t* __restrict__ stream,
                                                                   const QTab* __restrict__ lut,
                                                                   uint32_t* __restrict__ summary,
@@ -41,6 +41,10 @@ __global__ __launch_bounds__(kSumThreads) void k_index_summarize(const FrameDev*
   __shared__ __attribute__((aligned(16))) uint8_t s_nc[kTabN];         // ... or chroma
   __shared__ uint16_t s_f[kChunk];                                     // macroblock length
   __shared__ uint32_t s_wave[kSumThreads / 64];
+  __shared__ uint16_t s_slot[2 * kEntries];  // first-hop targets: marker, then index into s_list
+  __shared__ uint16_t s_list[kEntries];      // the distinct first-hop targets
+  __shared__ uint32_t s_res[kEntries];       // (macroblocks << 16) | exit offset of each distinct target
+  __shared__ uint32_t s_grp[12];
 
   const FrameDev f = frames[blockIdx.y];
   const uint32_t c = blockIdx.x;
@@ -172,16 +176,60 @@ __global__ __launch_bounds__(kSumThreads) void k_index_summarize(const FrameDev*
     s_f[p] = (uint16_t)(q - p);
   }
   __syncthreads();
-  // ---- 5. walk every possible entry offset to the end of the chunk ----
+  // ---- 5. every possible entry offset walked to the end of the chunk ----
+  // The 384 trails merge almost at once (after one macroblock a few dozen distinct positions are
+  // left), so each entry takes one hop, the distinct targets are compacted, only those are walked
+  // to the end, and every entry picks up the result of its target.
   uint32_t* out = summary + (size_t)(f.sum_base + c) * kEntries;
-  for (int e = tid; e < kEntries; e += kSumThreads) {
-    uint32_t p = e, cnt = 0;
-    while (p < (uint32_t)kChunk) {
-      p += s_f[p];
-      cnt++;
+  constexpr int kHopN = 2 * kEntries;  // a first hop lands below this
+  static_assert(kHopN == 3 * kSumThreads && kEntries <= 2 * kSumThreads, "compaction layout");
+  const bool two = tid + kSumThreads < kEntries;
+  const uint32_t h0 = tid + s_f[tid], h1 = two ? tid + kSumThreads + s_f[tid + kSumThreads] : h0;
+  for (int i = tid; i < kHopN; i += kSumThreads) s_slot[i] = 0xFFFFu;
+  __syncthreads();
+  s_slot[h0] = 0;
+  s_slot[h1] = 0;
+  __syncthreads();
+  {
+    // compaction of the marked positions, in position order: group g = k*4 + wave covers 64 positions
+    unsigned long long m[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      m[k] = __ballot(s_slot[k * kSumThreads + tid] != 0xFFFFu);
+      if (lane == 0) s_grp[k * 4 + wv] = (uint32_t)__popcll(m[k]);
     }
-    out[e] = (cnt << 16) | (p - (uint32_t)kChunk);
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int g = 0; g < 12; g++) {
+      const uint32_t n = s_grp[g];
+      total += n;
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      base = 0;
+#pragma unroll
+      for (int g = 0; g < 12; g++) base += g < k * 4 + wv ? s_grp[g] : 0u;
+      if ((m[k] >> lane) & 1ull) {
+        const uint32_t idx = base + (uint32_t)__popcll(m[k] & below);
+        s_list[idx] = (uint16_t)(k * kSumThreads + tid);
+        s_slot[k * kSumThreads + tid] = (uint16_t)idx;
+      }
+    }
+    __syncthreads();
+    for (uint32_t u = tid; u < total; u += kSumThreads) {
+      uint32_t p = s_list[u], cnt = 1;  // the hop that led here is counted
+      while (p < (uint32_t)kChunk) {
+        p += s_f[p];
+        cnt++;
+      }
+      s_res[u] = (cnt << 16) | (p - (uint32_t)kChunk);
+    }
+    __syncthreads();
   }
+  out[tid] = s_res[s_slot[h0]];
+  if (two) out[tid + kSumThreads] = s_res[s_slot[h1]];
 }
 
 // One workgroup per packet.  Summaries are pulled through LDS a tile at a time; lane 0 chains them.

@@ -4,7 +4,7 @@
 set -u
 cd "$(dirname "$0")/.."
 mkdir -p gmerlin-avdecoder_amd/lib/ab
-declare -A V=( [base]="" [packed]="-DMIRTJ_SEARCH_PACKED" [unroll4]="-DMIRTJ_SEARCH_UNROLL=4" )
+declare -A V=( [base]="" [walk_all]="-DMIRTJ_WALK_ALL" )
 if [ "${1:-build}" = build ]; then
   for k in "${!V[@]}"; do
     MI_RTJ_CFLAGS="${V[$k]}" python -c "
