@@ -38,6 +38,7 @@ struct mi_rtj_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   QTab* d_lut = nullptr;
+  uint8_t b8[kNumQTab][2] = {};  // host copy of (lb8, cb8) per LUT row
   std::string err;
   // RTjpeg_t's header-driven state (lib/RTjpeg.c:3568-3579)
   int width = 0, height = 0, Q = 0;
@@ -67,6 +68,7 @@ struct mi_rtj_plan {
   bool profile = false;
   bool serial_index = false;        // MI_RTJ_INDEX=serial: one wave per packet (A/B baseline)
   bool emit_walk = false;           // MI_RTJ_EMIT=walk: per-chunk re-walk instead of the length tables
+  bool one_block_type = false;      // every frame's tables have lb8 == cb8: single-search summarize
   std::vector<Timed> ev[MI_RTJ_NUM_KERNELS];  // one pair per launch while profiling
   int launches = 0;
 };
@@ -142,7 +144,9 @@ int plan_alloc_chunks(mi_rtj_plan* p) {
   mi_rtj_ctx* c = p->ctx;
   uint64_t chunks = 0, entries = 0;
   p->max_chunks = 0;
+  p->one_block_type = true;
   for (auto& f : p->h_frames) {
+    p->one_block_type = p->one_block_type && c->b8[f.qidx][0] == c->b8[f.qidx][1];
     f.sum_base = (uint32_t)chunks;
     f.chunk_base = (uint32_t)entries;
     chunks += f.nchunks;
@@ -207,8 +211,12 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
     if ((rc = end(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
   } else {
     if ((rc = begin(MI_RTJ_K_SUMMARIZE)) != MI_RTJ_OK) return rc;
-    hipLaunchKernelGGL(k_index_summarize, dim3(p->max_chunks, p->n), dim3(kSumThreads), 0, c->stream, p->d_frames, st,
-                       c->d_lut, p->d_summary, p->d_lentab);
+    if (p->one_block_type)
+      hipLaunchKernelGGL(k_index_summarize<1>, dim3(p->max_chunks, p->n), dim3(kSumThreads), 0, c->stream, p->d_frames,
+                         st, c->d_lut, p->d_summary, p->d_lentab);
+    else
+      hipLaunchKernelGGL(k_index_summarize<2>, dim3(p->max_chunks, p->n), dim3(kSumThreads), 0, c->stream, p->d_frames,
+                         st, c->d_lut, p->d_summary, p->d_lentab);
     if ((rc = end(MI_RTJ_K_SUMMARIZE)) != MI_RTJ_OK) return rc;
     if ((rc = begin(MI_RTJ_K_RESOLVE)) != MI_RTJ_OK) return rc;
     hipLaunchKernelGGL(k_index_resolve, dim3(p->n), dim3(256), 0, c->stream, p->d_frames, p->d_summary,
@@ -283,6 +291,10 @@ mi_rtj_ctx* mi_rtj_create(int device) {
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
   std::vector<QTab> lut(kNumQTab);
   build_all_qtabs(lut.data());
+  for (int q = 0; q < kNumQTab; q++) {
+    c->b8[q][0] = (uint8_t)lut[q].lb8;
+    c->b8[q][1] = (uint8_t)lut[q].cb8;
+  }
   if ((e = hipMalloc((void**)&c->d_lut, sizeof(QTab) * kNumQTab)) != hipSuccess) return bail("hipMalloc(lut)", e);
   if ((e = hipMemcpy(c->d_lut, lut.data(), sizeof(QTab) * kNumQTab, hipMemcpyHostToDevice)) != hipSuccess)
     return bail("hipMemcpy(lut)", e);

@@ -30,6 +30,55 @@ constexpr int kSumThreads = 256;
 #endif
 constexpr int kSearchUnroll = MIRTJ_SEARCH_UNROLL;
 
+// Block length at every table position for NT (1 or 2) distinct block types; see step 3 of
+// k_index_summarize for the method.
+template <int NT>
+__device__ __forceinline__ void search_lengths(const uint16_t* s_w, const uint8_t* s_b, uint8_t* s_nl, uint8_t* s_nc,
+                                               uint32_t lb8, uint32_t cb8, int tid) {
+  const uint32_t bt8v[2] = {lb8, cb8}, needv[2] = {63u - lb8, 63u - cb8};
+  for (int i0 = tid; i0 < kTabN; i0 += kSumThreads * kSearchUnroll) {
+    uint32_t addr[kSearchUnroll][NT], tgt[kSearchUnroll][NT];
+#pragma unroll
+    for (int u = 0; u < kSearchUnroll; u++) {
+      const uint32_t i = (uint32_t)min(i0 + u * kSumThreads, kTabN - 1);
+#pragma unroll
+      for (int t = 0; t < NT; t++) {
+        addr[u][t] = 2u * (i + bt8v[t]);  // byte address of W[iq]
+        tgt[u][t] = (uint32_t)s_w[i + bt8v[t]] + needv[t];
+      }
+    }
+#pragma unroll
+    for (int step = 32; step >= 1; step >>= 1) {
+#pragma unroll
+      for (int u = 0; u < kSearchUnroll; u++) {
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+          const uint32_t w = *(const uint16_t*)((const uint8_t*)s_w + addr[u][t] + 2 * step);
+          const uint32_t below = ((w - tgt[u][t]) >> 15) & 1u;  // sums differ by < 2^15, compared mod 2^16
+          addr[u][t] += below * (2u * (uint32_t)step);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kSearchUnroll; u++) {
+      const int i = i0 + u * kSumThreads;
+      if (i < kTabN) {
+        uint32_t len[2];
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+          const uint32_t e = addr[u][t] / 2u + 1u;  // index of the block's last byte
+          len[t] = needv[t] ? e + 1u - (uint32_t)i : 64u;
+        }
+        if (NT == 1) len[1] = len[0];
+        if (s_b[i] == 0xFFu) len[0] = len[1] = 1u;
+        s_nl[i] = (uint8_t)len[0];
+        s_nc[i] = (uint8_t)len[1];
+      }
+    }
+  }
+}
+
+template <int NT>
 __global__ __launch_bounds__(kSumThreads, 5) void k_index_summarize(const FrameDev* __restrict__ frames,
                                                                   const uint8_t* __restrict__ stream,
                                                                   const QTab* __restrict__ lut,
@@ -108,46 +157,9 @@ __global__ __launch_bounds__(kSumThreads, 5) void k_index_summarize(const FrameD
   // full 1..64 window is exact for any need <= 63 because the predicate is monotone.
   // kSearchUnroll positions x 2 types are searched together so that their dependent reads overlap.
   const uint32_t lb8 = (uint32_t)lut[f.qidx].lb8, cb8 = (uint32_t)lut[f.qidx].cb8;
-  const uint32_t bt8v[2] = {lb8, cb8}, needv[2] = {63u - lb8, 63u - cb8};
-  for (int i0 = tid; i0 < kTabN; i0 += kSumThreads * kSearchUnroll) {
-    uint32_t addr[kSearchUnroll][2], tgt[kSearchUnroll][2];
-#pragma unroll
-    for (int u = 0; u < kSearchUnroll; u++) {
-      const uint32_t i = (uint32_t)min(i0 + u * kSumThreads, kTabN - 1);
-#pragma unroll
-      for (int t = 0; t < 2; t++) {
-        addr[u][t] = 2u * (i + bt8v[t]);  // byte address of W[iq]
-        tgt[u][t] = (uint32_t)s_w[i + bt8v[t]] + needv[t];
-      }
-    }
-#pragma unroll
-    for (int step = 32; step >= 1; step >>= 1) {
-#pragma unroll
-      for (int u = 0; u < kSearchUnroll; u++) {
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-          const uint32_t w = *(const uint16_t*)((const uint8_t*)s_w + addr[u][t] + 2 * step);
-          const uint32_t below = ((w - tgt[u][t]) >> 15) & 1u;  // sums differ by < 2^15, compared mod 2^16
-          addr[u][t] += below * (2u * (uint32_t)step);
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < kSearchUnroll; u++) {
-      const int i = i0 + u * kSumThreads;
-      if (i < kTabN) {
-        uint32_t len[2];
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-          const uint32_t e = addr[u][t] / 2u + 1u;  // index of the block's last byte
-          len[t] = needv[t] ? e + 1u - (uint32_t)i : 64u;
-        }
-        if (s_b[i] == 0xFFu) len[0] = len[1] = 1u;
-        s_nl[i] = (uint8_t)len[0];
-        s_nc[i] = (uint8_t)len[1];
-      }
-    }
-  }
+  // NT == 1: every packet of the launch has lb8 == cb8 (true for two thirds of the qualities, Q below
+  // ~171), so one search serves both block types; the host picks the instantiation per plan.
+  search_lengths<NT>(s_w, s_b, s_nl, s_nc, lb8, cb8, tid);
   __syncthreads();
 
   // both lengths of the chunk's own positions go to HBM for k_index_emit: (luma | chroma << 8)
