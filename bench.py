@@ -194,7 +194,8 @@ def main():
             "mpixels_per_s": round(fps * w * h / 1e6, 1),
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "alg_bytes_per_launch": kernels[dom]["alg_bytes"], "ms_per_launch": kernels[dom]["ms"]},
+                         "alg_bytes_per_launch": kernels[dom]["alg_bytes"], "ms_per_launch": kernels[dom]["ms"],
+                         "note": "integer-VALU-issue bound, not HBM bound: DESIGN.md section 5"},
             "roofline_decode": {"bound": "hbm", "kernel": "k_decode", "achieved": dec["gbs"], "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": round((dec["gbs"] or 0.0) / HBM_PEAK_GBS, 5),
                                 "ms_per_launch": dec["ms"], "alg_bytes_per_launch": alg_bytes},
