@@ -5,13 +5,16 @@
 // The index is therefore built in three launches that break the chain at fixed byte positions:
 //
 //   k_index_summarize  per chunk of kChunk stream bytes: length of a block of either type at
-//                      EVERY byte position (prefix sums of token weights + a bounded binary
-//                      search), composed into "next macroblock" jumps, then all kEntries possible
-//                      entry offsets are walked to the chunk's end -> (exit offset, MB count).
+//                      EVERY byte position (prefix sums of token weights + a bit-by-bit search
+//                      of the 64-byte window), composed into "next macroblock" jumps; every one
+//                      of the kEntries possible entry offsets takes one jump, the distinct targets
+//                      are walked to the chunk's end -> (exit offset, MB count) per entry.  The
+//                      block lengths are left in HBM for k_index_emit.
 //   k_index_resolve    per packet: chains the chunk summaries (one short serial walk in LDS) to
 //                      the true entry offset and first macroblock number of every chunk.
-//   k_index_emit       per chunk: one wave walks the true chain from the chunk's entry and
-//                      writes the byte offset of every block (rtj_decode_kernels.h walker).
+//   k_index_emit       per chunk: macroblock jumps from the stored lengths, one serial walk over
+//                      the chunk's own macroblocks from its true entry, then the byte offset of
+//                      every block.  (k_index_emit_walk re-walks the stream bytes instead: A/B.)
 //
 // Block-length rule (lib/RTjpeg.c:157-186, 2704): first byte 0xFF -> 1 byte; otherwise 1 DC byte,
 // bt8 raw bytes, then tokens until 63-bt8 coefficient slots are covered, a token 64..127 covering
