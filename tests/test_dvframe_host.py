@@ -1,0 +1,231 @@
+"""Host-side DV DIF-frame handling (include/mi_dvframe.h).  PARITY UNPINNED:
+the reference's lib/dvframe.c cannot be built here (gavl), so these tests compare the C module with
+an independent numpy restatement of the same lines on synthetic DIF frames built to the layout the
+code assumes, plus a few hand-made anchors."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from pkg import ROOT
+
+LIB = os.path.join(ROOT, "gmerlin-avdecoder_amd", "lib", "libmi_dvframe.so")
+u8p = C.POINTER(C.c_uint8)
+
+
+class Profile(C.Structure):
+    _fields_ = [("dsf", C.c_int), ("video_stype", C.c_int), ("frame_size", C.c_int), ("difseg_size", C.c_int),
+                ("n_difchan", C.c_int), ("frame_rate", C.c_int), ("frame_rate_base", C.c_int), ("ltc_divisor", C.c_int),
+                ("width", C.c_int), ("height", C.c_int), ("sar", (C.c_int * 2) * 2), ("pix_fmt", C.c_int), ("bpm", C.c_int),
+                ("audio_stride", C.c_int), ("audio_min_samples", C.c_int * 3),
+                ("audio_shuffle", C.POINTER(C.c_uint16 * 9))]
+
+
+@pytest.fixture(scope="module")
+def L():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "gmerlin-avdecoder_amd", "csrc"),
+                    os.path.join(ROOT, "gmerlin-avdecoder_amd", "lib", "libmi_dvframe.so")], check=True, capture_output=True)
+    lib = C.CDLL(LIB)
+    lib.mi_dv_frame_profile.restype = C.POINTER(Profile)
+    lib.mi_dv_frame_profile.argtypes = [u8p]
+    lib.mi_dv_profile_at.restype = C.POINTER(Profile)
+    lib.mi_dv_video_packet.argtypes = [C.POINTER(Profile), u8p, u8p, C.POINTER(C.c_int)]
+    lib.mi_dv_extract_audio.argtypes = [C.POINTER(Profile), u8p, C.POINTER(u8p)]
+    lib.mi_dv_audio_12to16.restype = C.c_uint16
+    lib.mi_dv_audio_12to16.argtypes = [C.c_uint16]
+    lib.mi_dv_audio_format.argtypes = [C.POINTER(Profile), u8p] + [C.POINTER(C.c_int)] * 3
+    lib.mi_dv_pixel_aspect.argtypes = [C.POINTER(Profile), u8p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.mi_dv_ssyb_pack.argtypes = [C.POINTER(Profile), u8p, C.c_int, u8p]
+    for n in ("mi_dv_date", "mi_dv_time"):
+        getattr(lib, n).argtypes = [C.POINTER(Profile), u8p] + [C.POINTER(C.c_int)] * 3
+    lib.mi_dv_timecode.argtypes = [C.POINTER(Profile), u8p] + [C.POINTER(C.c_int)] * 4
+    return lib
+
+
+def ptr(a):
+    return a.ctypes.data_as(u8p)
+
+
+def make_frame(p, rng, quant=0, freq=0, smpls=20, astype=0, apt=0):
+    f = rng.integers(0, 256, p.frame_size, dtype=np.uint8)
+    f[3] = (f[3] & 0x7F) | (p.dsf << 7)
+    f[80 * 5 + 48 + 3] = (f[80 * 5 + 48 + 3] & 0xE0) | p.video_stype
+    f[5] = (f[5] & 0xF8) | apt
+    f[4] = (f[4] & 0xF8)
+    o = 80 * 6 + 80 * 16 * 3 + 3  # audio source pack
+    f[o:o + 5] = [0x50, smpls, 0, astype, (freq << 3) | quant]
+    return f
+
+
+def np_12to16(s):
+    s = s if s < 0x800 else s | 0xF000
+    sh = (s & 0xF00) >> 8
+    if sh < 2 or sh > 0xD:
+        return s & 0xFFFF
+    if sh < 8:
+        sh -= 1
+        return ((s - 256 * sh) << sh) & 0xFFFF
+    sh = 0xE - sh
+    return (((s + 256 * sh + 1) << sh) - 1) & 0xFFFF
+
+
+def np_extract_audio(p, f, have):
+    """Independent restatement of dv_extract_audio (lib/dvframe.c:545-628)."""
+    shuffle = [[p.audio_shuffle[i][j] for j in range(9)] for i in range(p.difseg_size)]
+    o = 80 * 6 + 80 * 16 * 3 + 3
+    smpls, freq, quant = int(f[o + 1]) & 0x3F, (int(f[o + 4]) >> 3) & 7, int(f[o + 4]) & 7
+    size = (p.audio_min_samples[freq] + smpls) * 4
+    half = p.difseg_size // 2
+    bufs = [np.full(size + 8192, 0xCD, np.uint8) if have[k] else None for k in range(4)]
+    ipcm = 2 if (p.height == 720 and ((int(f[1]) >> 2) & 3) == 0) else 0
+    pcm = bufs[ipcm]
+    ipcm += 1
+    pos = 0
+    for chan in range(p.n_difchan):
+        stop = False
+        for i in range(p.difseg_size):
+            pos += 6 * 80
+            if quant == 1 and i == half:
+                pcm = bufs[ipcm] if ipcm < 4 else None
+                ipcm += 1
+                if pcm is None:
+                    stop = True
+                    break
+            for j in range(9):
+                d = 8
+                while d < 80:
+                    if quant == 0:
+                        of = shuffle[i][j] + (d - 8) // 2 * p.audio_stride
+                        if of * 2 < size:
+                            pcm[of * 2], pcm[of * 2 + 1] = f[pos + d + 1], f[pos + d]
+                            if pcm[of * 2 + 1] == 0x80 and pcm[of * 2] == 0:
+                                pcm[of * 2 + 1] = 0
+                    else:
+                        lc = (int(f[pos + d]) << 4) | (int(f[pos + d + 2]) >> 4)
+                        rc = (int(f[pos + d + 1]) << 4) | (int(f[pos + d + 2]) & 0xF)
+                        lc = 0 if lc == 0x800 else np_12to16(lc)
+                        rc = 0 if rc == 0x800 else np_12to16(rc)
+                        of = shuffle[i % half][j] + (d - 8) // 3 * p.audio_stride
+                        if of * 2 < size:
+                            pcm[of * 2], pcm[of * 2 + 1] = lc & 0xFF, lc >> 8
+                            of = shuffle[i % half + half][j] + (d - 8) // 3 * p.audio_stride
+                            pcm[of * 2], pcm[of * 2 + 1] = rc & 0xFF, rc >> 8
+                            d += 1
+                    d += 2
+                pos += 16 * 80
+        if stop:
+            break
+        pcm = bufs[ipcm] if ipcm < 4 else None
+        ipcm += 1
+        if pcm is None:
+            break
+    return size // 4, bufs
+
+
+def test_profiles_and_detection(L):
+    n = L.mi_dv_num_profiles()
+    assert n == 9
+    rng = np.random.default_rng(0)
+    sizes = []
+    for i in range(n):
+        p = L.mi_dv_profile_at(i).contents
+        sizes.append(p.frame_size)
+        assert p.frame_size == p.n_difchan * p.difseg_size * 150 * 80
+        f = make_frame(p, rng, apt=1 if i == 2 else 0)
+        got = L.mi_dv_frame_profile(ptr(f)).contents
+        assert (got.frame_size, got.width, got.height, got.pix_fmt) == (p.frame_size, p.width, p.height, p.pix_fmt), i
+    assert sizes == [120000, 144000, 144000, 240000, 288000, 480000, 576000, 240000, 288000]
+    ntsc = L.mi_dv_profile_at(0).contents  # BASELINE cfg 3: DV NTSC 720x480, 120000-byte frames, 4:1:1
+    assert (ntsc.width, ntsc.height, ntsc.pix_fmt, ntsc.bpm, ntsc.frame_rate, ntsc.frame_rate_base) == (720, 480, 0, 6, 30000, 1001)
+    bad = make_frame(ntsc, rng)
+    bad[80 * 5 + 48 + 3] = 0x1F
+    assert not L.mi_dv_frame_profile(ptr(bad))
+
+
+def test_video_packet_is_the_dif_frame(L):
+    rng = np.random.default_rng(1)
+    p = L.mi_dv_profile_at(0)
+    f = make_frame(p.contents, rng)
+    out = np.zeros(p.contents.frame_size, np.uint8)
+    key = C.c_int(0)
+    assert L.mi_dv_video_packet(p, ptr(f), ptr(out), C.byref(key)) == 120000
+    assert key.value == 1 and np.array_equal(out, f)
+
+
+def test_12_to_16_expansion(L):
+    for s in range(0, 0x1000):
+        assert L.mi_dv_audio_12to16(s) == np_12to16(s), s
+    assert L.mi_dv_audio_12to16(0x000) == 0 and L.mi_dv_audio_12to16(0x1FF) == 0x1FF
+    assert L.mi_dv_audio_12to16(0x7FF) == 0x7FC0 and L.mi_dv_audio_12to16(0x800) == 0x803F  # +full / error code
+
+
+@pytest.mark.parametrize("pi,quant,freq", [(0, 0, 0), (0, 0, 1), (0, 1, 2), (1, 0, 0), (1, 1, 2), (3, 0, 0), (6, 0, 0), (7, 0, 0)])
+def test_audio_deshuffle(L, pi, quant, freq):
+    rng = np.random.default_rng(10 * pi + quant)
+    pp = L.mi_dv_profile_at(pi)
+    p = pp.contents
+    f = make_frame(p, rng, quant=quant, freq=freq, smpls=int(rng.integers(0, 40)))
+    f[1] = (f[1] & 0xF3) | 0x04  # 720p: an odd half-frame -> channel pairs 0,1
+    npairs = 2 if (quant == 1 or p.n_difchan >= 2) else 1
+    have = [k < max(npairs, p.n_difchan) for k in range(4)]
+    want_n, want = np_extract_audio(p, f, have)
+    bufs = [np.full(w.size, 0xCD, np.uint8) if w is not None else None for w in want]
+    arr = (u8p * 4)(*[ptr(b) if b is not None else None for b in bufs])
+    assert L.mi_dv_extract_audio(pp, ptr(f), arr) == want_n
+    for k in range(4):
+        if bufs[k] is not None:
+            assert np.array_equal(bufs[k], want[k]), k
+    sr, ch, mx = C.c_int(), C.c_int(), C.c_int()
+    assert L.mi_dv_audio_format(pp, ptr(f), C.byref(sr), C.byref(ch), C.byref(mx)) == 1
+    assert sr.value == (48000, 44100, 32000)[freq] and mx.value == p.audio_min_samples[freq] + 63
+
+
+def test_no_audio_and_bad_quantisation(L):
+    rng = np.random.default_rng(3)
+    pp = L.mi_dv_profile_at(0)
+    f = make_frame(pp.contents, rng)
+    buf = np.zeros(16384, np.uint8)
+    arr = (u8p * 4)(ptr(buf), None, None, None)
+    f[80 * 6 + 80 * 16 * 3 + 3] = 0x51  # not an audio source pack
+    assert L.mi_dv_extract_audio(pp, ptr(f), arr) == 0
+    f[80 * 6 + 80 * 16 * 3 + 3] = 0x50
+    f[80 * 6 + 80 * 16 * 3 + 3 + 4] = 0x02  # quantisation 2
+    assert L.mi_dv_extract_audio(pp, ptr(f), arr) == -1
+
+
+def test_subcode_packs_date_time_timecode_aspect(L):
+    rng = np.random.default_rng(4)
+    pp = L.mi_dv_profile_at(1)
+    f = make_frame(pp.contents, rng)
+    # wipe every subcode packet id, then plant three packs in different sequences / blocks / slots
+    for i in range(12):
+        for j in range(2):
+            for k in range(6):
+                f[i * 12000 + 80 + j * 80 + 3 + k * 8 + 3] = 0xFF
+
+    def plant(i, j, k, data):
+        o = i * 12000 + 80 + j * 80 + 3 + k * 8 + 3
+        f[o:o + 5] = data
+
+    plant(3, 1, 4, [0x62, 0x00, 0x27, 0x11, 0x99])  # 27 November 1999
+    plant(0, 0, 2, [0x63, 0x00, 0x58, 0x34, 0x12])  # 12:34:58
+    plant(7, 1, 5, [0x13, 0x24, 0x41, 0x07, 0x21])  # 21:07:41 frame 24
+    y, m, d = C.c_int(), C.c_int(), C.c_int()
+    assert L.mi_dv_date(pp, ptr(f), C.byref(y), C.byref(m), C.byref(d)) == 1 and (y.value, m.value, d.value) == (1999, 11, 27)
+    assert L.mi_dv_time(pp, ptr(f), C.byref(y), C.byref(m), C.byref(d)) == 1 and (y.value, m.value, d.value) == (12, 34, 58)
+    fr = C.c_int()
+    assert L.mi_dv_timecode(pp, ptr(f), C.byref(y), C.byref(m), C.byref(d), C.byref(fr)) == 1
+    assert (y.value, m.value, d.value, fr.value) == (21, 7, 41, 24)
+    pk = np.zeros(5, np.uint8)
+    assert L.mi_dv_ssyb_pack(pp, ptr(f), 0x55, ptr(pk)) == 0
+    # pixel aspect: 4:3 unless the video control pack says 16:9
+    num, den = C.c_int(), C.c_int()
+    o = 80 * 5 + 48 + 5
+    f[o], f[o + 2] = 0x61, 0x00
+    L.mi_dv_pixel_aspect(pp, ptr(f), C.byref(num), C.byref(den))
+    assert (num.value, den.value) == (59, 54)
+    f[o + 2] = 0x02
+    L.mi_dv_pixel_aspect(pp, ptr(f), C.byref(num), C.byref(den))
+    assert (num.value, den.value) == (118, 81)
