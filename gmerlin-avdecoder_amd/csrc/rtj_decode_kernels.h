@@ -187,11 +187,16 @@ constexpr int kDecThreads = 64;
 #ifndef MIRTJ_DEC_WAVES
 #define MIRTJ_DEC_WAVES 1
 #endif
+#ifndef MIRTJ_DEC_ITERS
+#define MIRTJ_DEC_ITERS 4
+#endif
 constexpr int kCoefStride = MIRTJ_COEF_STRIDE;  // int16 per lane: 64 + 8 pad (144 B, conflict-free b128 reads)
+constexpr int kDecIters = MIRTJ_DEC_ITERS;      // macroblock groups a wave works through, one after the other
 
 // ---------------------------------------------------------------------------------------
-// k_decode: grid (3 * groups rounded up to 8, frames), one wave per workgroup.  A group is kMbPerGroup
-// consecutive macroblocks; its three waves take
+// k_decode: grid (3 * slots, frames), one wave per workgroup; slots = groups / kDecIters rounded up
+// to a multiple of 8.  A group is kMbPerGroup consecutive macroblocks; a wave owns one PART of
+// kDecIters groups (slot, slot + slots, ...):
 //   part 0: the 64 upper luma blocks (Y0,Y1 of each MB), part 1: the 64 lower ones,
 //   part 2: 32 Cb + 32 Cr blocks.
 // Lanes of a wave hold horizontally adjacent blocks, so every row store of a wave covers 512
@@ -199,6 +204,11 @@ constexpr int kCoefStride = MIRTJ_COEF_STRIDE;  // int16 per lane: 64 + 8 pad (1
 // stream (neighbouring lanes read neighbouring bytes, so the wave's loads stay within a few
 // cache lines), parses them into a private LDS scratch (transposed, so a column is one 16-byte
 // read), then runs both transform passes entirely in registers.
+//
+// A wave works through several groups so that it can request the next group's block offset before
+// parsing and the next group's stream bytes before transforming: only the first group pays the
+// three dependent loads (descriptor -> block offset -> stream bytes).  Measured: 2 % over one
+// group per wave; eight groups per wave lose it again (fewer, longer waves balance worse).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const FrameDev* __restrict__ frames,
                                                          const uint8_t* __restrict__ stream,
@@ -209,15 +219,14 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
   __shared__ uint32_t s_tab[64];  // per zig-zag slot: (dequantiser << 8) | transposed position
 
   const FrameDev f = frames[blockIdx.y];
-  // part-major numbering with the group count padded to a multiple of 8: the three waves of a
-  // group get linear ids that differ by a multiple of 8, i.e. (as workgroups are dealt round-robin
-  // to the 8 XCDs) they share one L2 and the group's stream bytes are fetched from HBM once
-  const uint32_t gpad = gridDim.x / 3u;
-  const uint32_t part = blockIdx.x / gpad, grp = blockIdx.x - part * gpad;
-  const uint32_t mb0 = grp * kMbPerGroup;
-  if (mb0 >= f.nmb) return;
+  // part-major numbering with the slot count a multiple of 8: the three waves that share a set
+  // of groups get linear ids that differ by a multiple of 8, i.e. (as workgroups are dealt
+  // round-robin to the 8 XCDs) they share one L2 and the stream bytes come from HBM once
+  const uint32_t slots = gridDim.x / 3u;
+  const uint32_t part = blockIdx.x / slots, slot = blockIdx.x - part * slots;
+  const uint32_t ngroups = (f.nmb + (uint32_t)kMbPerGroup - 1u) / (uint32_t)kMbPerGroup;
+  if (slot >= ngroups) return;
   const int lane = threadIdx.x;
-  const uint32_t mb_end = min(mb0 + (uint32_t)kMbPerGroup, f.nmb);
   const uint32_t* off = blkoff + f.blk_base;
   const QTab& qt = lut[f.qidx];
   const int chroma = part == 2u;
@@ -228,137 +237,170 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
   }
   __syncthreads();  // one wave: orders the table write before the lanes' reads
   const uint32_t bt8 = (uint32_t)(chroma ? qt.cb8 : qt.lb8);
-
-  // ---- which block is mine ----
-  uint32_t mb, kblk;
-  if (!chroma) {
-    mb = mb0 + (lane >> 1);
-    kblk = 2u * part + (lane & 1);
-  } else {
-    mb = mb0 + (lane & 31);
-    kblk = 4u + (lane >> 5);
-  }
-  if (mb >= mb_end) return;  // no barriers below
-
-  // ---- stream -> dequantised coefficients, int16, transposed (lib/RTjpeg.c:157-186) ----
-  // The block's bytes are pulled 16 at a time into registers (aligned dwords + a byte funnel
-  // shift), so the only loop-carried dependency is the coefficient counter; table reads and
-  // scratch writes of the 16 byte slots are independent and pipeline through the LDS.
-  // Bytes at or past data_len read as 0.
-  const uint32_t pos0 = off[6u * mb + kblk];  // block start relative to the first data byte
-  const uint8_t* gsrc = stream + f.data_off + pos0;
-  const uint32_t sh = (uint32_t)((uintptr_t)gsrc & 3u);
-  const uint32_t* g4 = (const uint32_t*)(gsrc - sh);
-  long long rel = (long long)pos0 - (long long)sh;  // position of g4[0]'s first byte
-  auto ld = [&](int k) -> uint32_t {
-    const long long r = rel + 4ll * k, rem = (long long)f.data_len - r;
-    uint32_t v = 0;
-    if (rem > 0) {
-      v = g4[k];
-      if (rem < 4) v &= (1u << (8 * (int)rem)) - 1u;
-    }
-    return v;
-  };
-  uint32_t d0 = ld(0), d1 = ld(1), d2 = ld(2), d3 = ld(3), d4 = ld(4);
-  if ((__builtin_amdgcn_alignbyte(d1, d0, sh) & 0xFFu) == 0xFFu) return;  // unchanged block (lib/RTjpeg.c:2704)
-
-  int16_t* my = s_coef + lane * kCoefStride;
-  {
-    uint4* z = (uint4*)my;
-#pragma unroll
-    for (int i = 0; i < 8; i++) z[i] = make_uint4(0, 0, 0, 0);
-  }
   const uint32_t* tab = s_tab;
-  uint32_t co = 0;    // next coefficient slot (zig-zag index)
-  uint32_t jbase = 0; // index of the round's first byte within the block
-  while (true) {
-    const uint32_t wd[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
-                            __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
-    // 16 bytes are in registers; they are consumed eight at a time so that short blocks stop early
-    // (here luma blocks are 13..24 bytes, chroma 2..5)
-    bool more = true;
+  int16_t* my = s_coef + lane * kCoefStride;
+
+  // ---- which block of a group is mine ----
+  const uint32_t dmb = chroma ? (uint32_t)(lane & 31) : (uint32_t)(lane >> 1);
+  const uint32_t kblk = chroma ? 4u + (uint32_t)(lane >> 5) : 2u * part + (uint32_t)(lane & 1);
+  const uint8_t* data = stream + f.data_off;
+
+  // the dword that holds stream byte `p` and the four after it, bytes at or past data_len read as 0
+  struct Bytes {
+    uint32_t d[5];
+  };
+  auto fetch = [&](uint32_t p) -> Bytes {
+    const uint8_t* g = data + p;
+    const uint32_t sh = (uint32_t)((uintptr_t)g & 3u);
+    const uint32_t* g4 = (const uint32_t*)(g - sh);
+    const long long rel = (long long)p - (long long)sh;  // position of g4[0]'s first byte
+    Bytes b;
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
-      if (more) {
+    for (int k = 0; k < 5; k++) {
+      const long long rem = (long long)f.data_len - (rel + 4ll * k);
+      uint32_t v = 0;
+      if (rem > 0) {
+        v = g4[k];
+        if (rem < 4) v &= (1u << (8 * (int)rem)) - 1u;
+      }
+      b.d[k] = v;
+    }
+    return b;
+  };
+
+  uint32_t grp = slot;
+  uint32_t mb = grp * (uint32_t)kMbPerGroup + dmb;
+  bool valid = mb < f.nmb;
+  uint32_t pos0 = valid ? off[6u * mb + kblk] : 0u;  // block start relative to the first data byte
+  Bytes cur = fetch(pos0);
+
+  for (int it = 0; it < kDecIters; it++) {
+    // ---- request the next group's block offset before anything else ----
+    const uint32_t grp_n = grp + slots;
+    const bool have_n = it + 1 < kDecIters && grp_n < ngroups;  // wave-uniform
+    const uint32_t mb_n = grp_n * (uint32_t)kMbPerGroup + dmb;
+    const bool valid_n = have_n && mb_n < f.nmb;
+    const uint32_t pos_n = valid_n ? off[6u * mb_n + kblk] : 0u;
+
+    const uint32_t sh = (uint32_t)((uintptr_t)(data + pos0) & 3u);
+    uint32_t d0 = cur.d[0], d1 = cur.d[1], d2 = cur.d[2], d3 = cur.d[3], d4 = cur.d[4];
+    // unchanged block: previous pixels stay (lib/RTjpeg.c:2704)
+    const bool live_blk = valid && (__builtin_amdgcn_alignbyte(d1, d0, sh) & 0xFFu) != 0xFFu;
+
+    if (live_blk) {
+      // ---- stream -> dequantised coefficients, int16, transposed (lib/RTjpeg.c:157-186) ----
+      // The block's bytes are consumed 16 at a time from registers (aligned dwords + a byte funnel
+      // shift), so the only loop-carried dependency is the coefficient counter; table reads and
+      // scratch writes of the byte slots are independent and pipeline through the LDS.
+      {
+        uint4* z = (uint4*)my;
 #pragma unroll
-        for (int t = 8 * half; t < 8 * half + 8; t++) {
-          const uint32_t j = jbase + t;
-          const uint32_t ub = (wd[t >> 2] >> (8 * (t & 3))) & 0xFFu;
-          const int sv = (int)(int8_t)ub;
-          const int val = j == 0u ? (int)ub : sv;                // DC is the only unsigned byte
-          const bool run = j > bt8 && sv > 63;                   // zero run of sv-63 slots (scratch is already 0)
-          const bool live = co < 64u;
-          const uint32_t e = tab[co & 63u];
-          const int prod = mul24(val, (int)(e >> 8));            // |val| < 2^8, dequantiser < 2^15
-          my[(live && !run) ? (e & 63u) : 64u] = (int16_t)prod;  // slot 64 is a write-only dump
-          co += run ? (uint32_t)(sv - 63) : 1u;
+        for (int i = 0; i < 8; i++) z[i] = make_uint4(0, 0, 0, 0);
+      }
+      uint32_t co = 0;      // next coefficient slot (zig-zag index)
+      uint32_t jbase = 0;   // index of the round's first byte within the block
+      uint32_t pnext = pos0;
+      while (true) {
+        const uint32_t wd[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
+                                __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
+        // 16 bytes are in registers; they are consumed eight at a time so that short blocks stop early
+        // (here luma blocks are 13..24 bytes, chroma 2..5)
+        bool more = true;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+          if (more) {
+#pragma unroll
+            for (int t = 8 * half; t < 8 * half + 8; t++) {
+              const uint32_t j = jbase + t;
+              const uint32_t ub = (wd[t >> 2] >> (8 * (t & 3))) & 0xFFu;
+              const int sv = (int)(int8_t)ub;
+              const int val = j == 0u ? (int)ub : sv;                // DC is the only unsigned byte
+              const bool run = j > bt8 && sv > 63;                   // zero run of sv-63 slots (scratch is already 0)
+              const bool live = co < 64u;
+              const uint32_t e = tab[co & 63u];
+              const int prod = mul24(val, (int)(e >> 8));            // |val| < 2^8, dequantiser < 2^15
+              my[(live && !run) ? (e & 63u) : 64u] = (int16_t)prod;  // slot 64 is a write-only dump
+              co += run ? (uint32_t)(sv - 63) : 1u;
+            }
+            more = __any(co < 64u);
+          }
         }
-        more = __any(co < 64u);
+        if (!more) break;
+        jbase += 16u;
+        pnext += 16u;
+        const Bytes nb = fetch(pnext);  // same alignment as pos0: nb.d[0] is the old d4
+        d0 = nb.d[0];
+        d1 = nb.d[1];
+        d2 = nb.d[2];
+        d3 = nb.d[3];
+        d4 = nb.d[4];
       }
     }
-    if (!more) break;
-    jbase += 16u;
-    g4 += 4;
-    rel += 16;
-    d0 = d4;
-    d1 = ld(1);
-    d2 = ld(2);
-    d3 = ld(3);
-    d4 = ld(4);
-  }
 
-  // ---- column pass: column c of the block is the c-th 16-byte piece of the scratch ----
-  int ws[8][8];
-#pragma unroll
-  for (int c = 0; c < 8; c++) {
-    const uint4 q = ((const uint4*)my)[c];
-    int x0 = (int)(int16_t)(q.x & 0xFFFFu), x1 = (int)q.x >> 16;
-    const int x2 = (int)(int16_t)(q.y & 0xFFFFu), x3 = (int)q.y >> 16;
-    const int x4 = (int)(int16_t)(q.z & 0xFFFFu), x5 = (int)q.z >> 16;
-    const int x6 = (int)(int16_t)(q.w & 0xFFFFu), x7 = (int)q.w >> 16;
-    if (c == 0) x0 += 4;  // DESCALE's rounding term, carried through both linear DC paths
-    int y[8];
-    idct8(x0, x1, x2, x3, x4, x5, x6, x7, y);
-#pragma unroll
-    for (int r = 0; r < 8; r++) ws[r][c] = y[r];
-  }
+    // ---- request the next group's stream bytes: they arrive while this group is transformed ----
+    Bytes nxt;
+    if (have_n) nxt = fetch(pos_n);
 
-  // ---- row pass + scatter ----
-  // macroblock coordinates without a per-lane division: one scalar division for the group's
-  // first macroblock, then at most one row wrap per lane when rows are at least a group wide
-  uint32_t mx, my_;
-  {
-    const uint32_t mbw = f.mbw;
-    const uint32_t gy = mb0 / mbw, gx = mb0 - gy * mbw;  // uniform
-    const uint32_t dx = mb - mb0;
-    if (mbw >= (uint32_t)kMbPerGroup) {
-      const bool wrap = gx + dx >= mbw;
-      mx = wrap ? gx + dx - mbw : gx + dx;
-      my_ = wrap ? gy + 1u : gy;
-    } else {
-      my_ = mb / mbw;
-      mx = mb - my_ * mbw;
+    if (live_blk) {
+      // ---- column pass: column c of the block is the c-th 16-byte piece of the scratch ----
+      int ws[8][8];
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const uint4 q = ((const uint4*)my)[c];
+        int x0 = (int)(int16_t)(q.x & 0xFFFFu), x1 = (int)q.x >> 16;
+        const int x2 = (int)(int16_t)(q.y & 0xFFFFu), x3 = (int)q.y >> 16;
+        const int x4 = (int)(int16_t)(q.z & 0xFFFFu), x5 = (int)q.z >> 16;
+        const int x6 = (int)(int16_t)(q.w & 0xFFFFu), x7 = (int)q.w >> 16;
+        if (c == 0) x0 += 4;  // DESCALE's rounding term, carried through both linear DC paths
+        int y[8];
+        idct8(x0, x1, x2, x3, x4, x5, x6, x7, y);
+#pragma unroll
+        for (int r = 0; r < 8; r++) ws[r][c] = y[r];
+      }
+
+      // ---- row pass + scatter ----
+      // macroblock coordinates without a per-lane division: one scalar division for the group's
+      // first macroblock, then at most one row wrap per lane when rows are at least a group wide
+      uint32_t mx, my_;
+      {
+        const uint32_t mbw = f.mbw, mb0 = grp * (uint32_t)kMbPerGroup;
+        const uint32_t gy = mb0 / mbw, gx = mb0 - gy * mbw;  // uniform
+        if (mbw >= (uint32_t)kMbPerGroup) {
+          const bool wrap = gx + dmb >= mbw;
+          mx = wrap ? gx + dmb - mbw : gx + dmb;
+          my_ = wrap ? gy + 1u : gy;
+        } else {
+          my_ = mb / mbw;
+          mx = mb - my_ * mbw;
+        }
+      }
+      uint8_t* dst;
+      uint32_t stride;
+      if (!chroma) {
+        stride = f.w;
+        dst = outbuf + f.out_off + (size_t)(16u * my_ + 8u * (kblk >> 1)) * stride + 16u * mx + 8u * (kblk & 1u);
+      } else {
+        stride = f.w >> 1;
+        const size_t ysz = (size_t)f.w * f.h;
+        dst = outbuf + f.out_off + ysz + (kblk == 5u ? ysz >> 2 : 0) + (size_t)(8u * my_) * stride + 8u * mx;
+      }
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        int y[8];
+        idct8(ws[r][0], ws[r][1], ws[r][2], ws[r][3], ws[r][4], ws[r][5], ws[r][6], ws[r][7], y);
+        uint2 o;
+        o.x = px(y[0]) | (px(y[1]) << 8) | (px(y[2]) << 16) | (px(y[3]) << 24);
+        o.y = px(y[4]) | (px(y[5]) << 8) | (px(y[6]) << 16) | (px(y[7]) << 24);
+        *(uint2*)dst = o;
+        dst += stride;
+      }
     }
-  }
-  uint8_t* dst;
-  uint32_t stride;
-  if (!chroma) {
-    stride = f.w;
-    dst = outbuf + f.out_off + (size_t)(16u * my_ + 8u * (kblk >> 1)) * stride + 16u * mx + 8u * (kblk & 1u);
-  } else {
-    stride = f.w >> 1;
-    const size_t ysz = (size_t)f.w * f.h;
-    dst = outbuf + f.out_off + ysz + (kblk == 5u ? ysz >> 2 : 0) + (size_t)(8u * my_) * stride + 8u * mx;
-  }
-#pragma unroll
-  for (int r = 0; r < 8; r++) {
-    int y[8];
-    idct8(ws[r][0], ws[r][1], ws[r][2], ws[r][3], ws[r][4], ws[r][5], ws[r][6], ws[r][7], y);
-    uint2 o;
-    o.x = px(y[0]) | (px(y[1]) << 8) | (px(y[2]) << 16) | (px(y[3]) << 24);
-    o.y = px(y[4]) | (px(y[5]) << 8) | (px(y[6]) << 16) | (px(y[7]) << 24);
-    *(uint2*)dst = o;
-    dst += stride;
+    if (!have_n) break;
+    grp = grp_n;
+    mb = mb_n;
+    valid = valid_n;
+    pos0 = pos_n;
+    cur = nxt;
   }
 }
 
