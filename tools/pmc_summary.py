@@ -13,7 +13,7 @@ acc = defaultdict(lambda: defaultdict(list))
 for path in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     with open(path) as fh:
         for row in csv.DictReader(fh):
-            k = row["Kernel_Name"].split("(")[0].replace("mirtj::", "")
+            k = row["Kernel_Name"].split("(")[0].replace("mirtj::", "").replace("void ", "").split("<")[0]
             acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {}
 for k, ctrs in sorted(acc.items()):
