@@ -4,7 +4,7 @@
 set -u
 cd "$(dirname "$0")/.."
 mkdir -p gmerlin-avdecoder_amd/lib/ab
-declare -A V=( [base]="" [unroll4]="-DMIRTJ_SEARCH_UNROLL=4" [emit128]="-DMIRTJ_EMIT_THREADS=128" [dec_it1]="-DMIRTJ_DEC_ITERS=1" )
+declare -A V=( [base]="" [f_plain]="-DMIRTJ_F_PLAIN" )
 if [ "${1:-build}" = build ]; then
   for k in "${!V[@]}"; do
     MI_RTJ_CFLAGS="${V[$k]}" python -c "
