@@ -294,6 +294,12 @@ mi_rtj_ctx* mi_rtj_create(int device) {
   for (int q = 0; q < kNumQTab; q++) {
     c->b8[q][0] = (uint8_t)lut[q].lb8;
     c->b8[q][1] = (uint8_t)lut[q].cb8;
+    // k_decode places DC and the raw bytes inside a block's first 16 bytes (the formula yields 0, 4, 8, 9)
+    if (lut[q].lb8 > kMaxRawBytes || lut[q].cb8 > kMaxRawBytes) {
+      fail(nullptr, MI_RTJ_ERR_ARG, "quantiser table %d has more than %d raw coefficients", q, kMaxRawBytes);
+      mi_rtj_destroy(c);
+      return nullptr;
+    }
   }
   if ((e = hipMalloc((void**)&c->d_lut, sizeof(QTab) * kNumQTab)) != hipSuccess) return bail("hipMalloc(lut)", e);
   if ((e = hipMemcpy(c->d_lut, lut.data(), sizeof(QTab) * kNumQTab, hipMemcpyHostToDevice)) != hipSuccess)

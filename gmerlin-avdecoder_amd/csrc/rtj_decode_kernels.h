@@ -11,6 +11,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "rtj_common.h"
 
 namespace mirtj {
@@ -170,6 +172,23 @@ __device__ __forceinline__ void idct8(int x0, int x1, int x2, int x3, int x4, in
   y[4] = e3 + o4; y[3] = e3 - o4;
 }
 
+// The same transform when x4..x7 are zero (every term they feed vanishes exactly: M(0,c) == 0 and
+// (-x)*(-669) == x*669), used when a whole wave's blocks keep their coefficients in the low 4x4.
+__device__ __forceinline__ void idct8_lo(int x0, int x1, int x2, int x3, int (&y)[8]) {
+  const int r26 = mulr8(x2, 362) - x2;
+  const int e0 = x0 + x2, e3 = x0 - x2, e1 = x0 + r26, e2 = x0 - r26;
+  const int o7 = x1 + x3, d13 = x1 - x3;
+  const int m = mulr8(d13, 362);
+  const int z5 = mulr8(d13, 473);
+  const int o6 = mulr8(x3, 669) + z5 - o7;
+  const int o5 = m - o6;
+  const int o4 = mulr8(x1, 277) - z5 + o5;
+  y[0] = e0 + o7; y[7] = e0 - o7;
+  y[1] = e1 + o6; y[6] = e1 - o6;
+  y[2] = e2 + o5; y[5] = e2 - o5;
+  y[4] = e3 + o4; y[3] = e3 - o4;
+}
+
 // DESCALE + int16 narrowing + clamp 16..235 (lib/RTjpeg.c:1201-1205).  The +4 rounding term
 // was folded into the DC coefficient before the column pass, so only the shift remains:
 // bits [18:3] sign-extended == (int16_t)(v >> 3).
@@ -178,6 +197,67 @@ __device__ __forceinline__ uint32_t px(int v) {
   s = s > 235 ? 235 : s;
   s = s < 16 ? 16 : s;
   return (uint32_t)s;
+}
+
+// LDS accesses by 32-bit byte address (the parse loop keeps addresses, not indices, in registers)
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+typedef __attribute__((address_space(3))) int16_t lds_i16_t;
+__device__ __forceinline__ uint32_t lds_address(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+// (signed or unsigned byte b of w) * (bits 31:16 of e): byte select, sign extension and the 16-bit
+// field select ride on the multiply (SDWA), so a coefficient costs one vector instruction
+__device__ __forceinline__ int mul_byte_hi16(uint32_t w, uint32_t e, int b, bool sign) {
+  int r;
+#define MIRTJ_MUL_SDWA(SRC0, SEL) \
+  asm("v_mul_i32_i24_sdwa %0, " SRC0 ", %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SEL " src1_sel:WORD_1" \
+      : "=v"(r) : "v"(w), "v"(e))
+  if (sign) {
+    switch (b) {
+      case 0: MIRTJ_MUL_SDWA("sext(%1)", "BYTE_0"); break;
+      case 1: MIRTJ_MUL_SDWA("sext(%1)", "BYTE_1"); break;
+      case 2: MIRTJ_MUL_SDWA("sext(%1)", "BYTE_2"); break;
+      default: MIRTJ_MUL_SDWA("sext(%1)", "BYTE_3"); break;
+    }
+  } else {
+    switch (b) {
+      case 0: MIRTJ_MUL_SDWA("%1", "BYTE_0"); break;
+      case 1: MIRTJ_MUL_SDWA("%1", "BYTE_1"); break;
+      case 2: MIRTJ_MUL_SDWA("%1", "BYTE_2"); break;
+      default: MIRTJ_MUL_SDWA("%1", "BYTE_3"); break;
+    }
+  }
+#undef MIRTJ_MUL_SDWA
+  return r;
+}
+
+// (signed byte b of w) - k: extraction, sign extension and the bias in one instruction
+__device__ __forceinline__ int sbyte_minus(uint32_t w, int b, int k) {
+  int r;
+#define MIRTJ_SUB_SDWA(SEL) \
+  asm("v_sub_u32_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SEL " src1_sel:DWORD" \
+      : "=v"(r) : "v"(w), "v"(k))
+  switch (b) {
+    case 0: MIRTJ_SUB_SDWA("BYTE_0"); break;
+    case 1: MIRTJ_SUB_SDWA("BYTE_1"); break;
+    case 2: MIRTJ_SUB_SDWA("BYTE_2"); break;
+    default: MIRTJ_SUB_SDWA("BYTE_3"); break;
+  }
+#undef MIRTJ_SUB_SDWA
+  return r;
+}
+
+__device__ __forceinline__ int med3_i32(int a, int b, int c) {
+  int r;
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+  return r;
+}
+
+// byte offset, within a lane's transposed coefficient scratch, of zig-zag slot k
+__host__ __device__ constexpr int slot_byte(int k) {
+  constexpr uint8_t z[64] = MIRTJ_ZZ_INIT;
+  return 2 * ((z[k] & 7) * 8 + (z[k] >> 3));
 }
 
 constexpr int kDecThreads = 64;
@@ -192,6 +272,9 @@ constexpr int kDecThreads = 64;
 #endif
 constexpr int kCoefStride = MIRTJ_COEF_STRIDE;  // int16 per lane: 64 + 8 pad (144 B, conflict-free b128 reads)
 constexpr int kDecIters = MIRTJ_DEC_ITERS;      // macroblock groups a wave works through, one after the other
+constexpr int kSlotTabN = 64 + 16;              // slot table: 64 coefficient slots, then "block finished" entries
+constexpr int kMaxRawBytes = 15;                // the host refuses tables with more leading 8-bit coefficients
+constexpr uint32_t kFetchSpan = 72;             // a block's loads stay below its start + this (64 + alignment + look-ahead)
 
 // ---------------------------------------------------------------------------------------
 // k_decode: grid (3 * slots, frames), one wave per workgroup; slots = groups / kDecIters rounded up
@@ -205,18 +288,34 @@ constexpr int kDecIters = MIRTJ_DEC_ITERS;      // macroblock groups a wave work
 // cache lines), parses them into a private LDS scratch (transposed, so a column is one 16-byte
 // read), then runs both transform passes entirely in registers.
 //
+// The kernel is bound by vector-instruction issue, so the parse loop is built to cost few
+// instructions per stream byte:
+//   * the slot table holds (dequantiser << 16 | scratch byte offset); byte select, sign extension
+//     and field select ride on the multiply and the address add (SDWA);
+//   * the slot counter is kept as the table's LDS address; "one slot, or the run length, and stop
+//     at 64" is one add, one shift-add and one median; entries past slot 63 point at a write-only
+//     dump with multiplier 0, so finished lanes need no predicate;
+//   * a zero run writes a 0 at its first slot instead of being predicated off (the scratch is
+//     zero already, and no slot is visited twice);
+//   * DC and the bt8 raw bytes sit at fixed slots: one multiply and one store at a constant
+//     offset each, per wave-uniform bt8 (0, 4, 8, 9 are the values the tables take);
+//   * the "past the packet's end reads as zero" masking is skipped when the whole wave's loads lie
+//     inside the packet (all but the last few blocks of a packet).
+// When no block of a wave has a coefficient outside the low 4x4 (chroma at high quality, flat
+// content), both passes run the four-input transform: four columns instead of eight.
+//
 // A wave works through several groups so that it can request the next group's block offset before
 // parsing and the next group's stream bytes before transforming: only the first group pays the
-// three dependent loads (descriptor -> block offset -> stream bytes).  Measured: 2 % over one
-// group per wave; eight groups per wave lose it again (fewer, longer waves balance worse).
+// three dependent loads (descriptor -> block offset -> stream bytes).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const FrameDev* __restrict__ frames,
                                                          const uint8_t* __restrict__ stream,
                                                          const QTab* __restrict__ lut,
                                                          const uint32_t* __restrict__ blkoff,
                                                          uint8_t* __restrict__ outbuf) {
-  __shared__ __attribute__((aligned(16))) int16_t s_coef[kDecThreads * kCoefStride];
-  __shared__ uint32_t s_tab[64];  // per zig-zag slot: (dequantiser << 8) | transposed position
+  constexpr int kCoefWords = kDecThreads * kCoefStride / 2;
+  __shared__ __attribute__((aligned(16))) uint32_t s_lds[kCoefWords + kSlotTabN];
+  uint32_t* s_tab = s_lds + kCoefWords;  // per zig-zag slot: (dequantiser << 16) | scratch byte offset
 
   const FrameDev f = frames[blockIdx.y];
   // part-major numbering with the slot count a multiple of 8: the three waves that share a set
@@ -232,29 +331,39 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
   const int chroma = part == 2u;
   {
     const int nat = c_zz[lane];
-    const int q = chroma ? qt.ciqt[nat] : qt.liqt[nat];
-    s_tab[lane] = ((uint32_t)q << 8) | (uint32_t)((nat & 7) * 8 + (nat >> 3));
+    const int q = chroma ? qt.ciqt[nat] : qt.liqt[nat];  // 0 .. 13984
+    s_tab[lane] = ((uint32_t)q << 16) | (uint32_t)(2 * ((nat & 7) * 8 + (nat >> 3)));
+    if (lane < kSlotTabN - 64) s_tab[64 + lane] = 128u;  // finished: multiplier 0, scratch slot 64 (write-only)
   }
   __syncthreads();  // one wave: orders the table write before the lanes' reads
   const uint32_t bt8 = (uint32_t)(chroma ? qt.cb8 : qt.lb8);
-  const uint32_t* tab = s_tab;
-  int16_t* my = s_coef + lane * kCoefStride;
+  const uint32_t my_a = lds_address(s_lds) + (uint32_t)lane * (uint32_t)(kCoefStride * 2);
+  const uint32_t tab_a = lds_address(s_tab);
+  const int ca_end = (int)tab_a + 4 * 64;  // slot counter (see below) of a finished block
+  const int k63 = 63;
+  const uint4* my = (const uint4*)((const uint8_t*)s_lds + (size_t)lane * (kCoefStride * 2));
 
   // ---- which block of a group is mine ----
   const uint32_t dmb = chroma ? (uint32_t)(lane & 31) : (uint32_t)(lane >> 1);
   const uint32_t kblk = chroma ? 4u + (uint32_t)(lane >> 5) : 2u * part + (uint32_t)(lane & 1);
   const uint8_t* data = stream + f.data_off;
 
-  // the dword that holds stream byte `p` and the four after it, bytes at or past data_len read as 0
+  // the dword that holds stream byte `p` and the four after it, bytes at or past data_len read as 0;
+  // `inside`: every lane's loads are known to lie inside the packet
   struct Bytes {
     uint32_t d[5];
   };
-  auto fetch = [&](uint32_t p) -> Bytes {
+  auto fetch = [&](uint32_t p, bool inside) -> Bytes {
     const uint8_t* g = data + p;
     const uint32_t sh = (uint32_t)((uintptr_t)g & 3u);
     const uint32_t* g4 = (const uint32_t*)(g - sh);
-    const long long rel = (long long)p - (long long)sh;  // position of g4[0]'s first byte
     Bytes b;
+    if (inside) {
+#pragma unroll
+      for (int k = 0; k < 5; k++) b.d[k] = g4[k];
+      return b;
+    }
+    const long long rel = (long long)p - (long long)sh;  // position of g4[0]'s first byte
 #pragma unroll
     for (int k = 0; k < 5; k++) {
       const long long rem = (long long)f.data_len - (rel + 4ll * k);
@@ -272,7 +381,9 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
   uint32_t mb = grp * (uint32_t)kMbPerGroup + dmb;
   bool valid = mb < f.nmb;
   uint32_t pos0 = valid ? off[6u * mb + kblk] : 0u;  // block start relative to the first data byte
-  Bytes cur = fetch(pos0);
+  bool inside = __all(pos0 + kFetchSpan <= f.data_len);  // wave-uniform
+  Bytes cur = fetch(pos0, inside);
+  bool try_lo = true;  // wave-uniform: test this wave's blocks for "low 4x4 only" until a test fails
 
   for (int it = 0; it < kDecIters; it++) {
     // ---- request the next group's block offset before anything else ----
@@ -290,75 +401,107 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
     if (live_blk) {
       // ---- stream -> dequantised coefficients, int16, transposed (lib/RTjpeg.c:157-186) ----
       // The block's bytes are consumed 16 at a time from registers (aligned dwords + a byte funnel
-      // shift), so the only loop-carried dependency is the coefficient counter; table reads and
-      // scratch writes of the byte slots are independent and pipeline through the LDS.
+      // shift), eight to a half round so that short blocks stop early.  The only loop-carried value
+      // is the slot counter `ca` = LDS address of the next slot's table entry.
       {
         uint4* z = (uint4*)my;
 #pragma unroll
         for (int i = 0; i < 8; i++) z[i] = make_uint4(0, 0, 0, 0);
       }
-      uint32_t co = 0;      // next coefficient slot (zig-zag index)
-      uint32_t jbase = 0;   // index of the round's first byte within the block
+      uint32_t wd[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
+                        __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
+      int ca = (int)tab_a + 4 * ((int)bt8 + 1);  // DC and the raw bytes have their slots fixed
+
+      // a token: one coefficient, or (64..127) a run of sv-63 zero slots (lib/RTjpeg.c:171-182)
+      auto token = [&](int t) {
+        const uint32_t w = wd[t >> 2];
+        const int svb = sbyte_minus(w, t & 3, k63);            // token - 63: > 0 for a run, its length
+        const uint32_t e = *(const lds_u32_t*)(uint32_t)ca;
+        int prod = mul_byte_hi16(w, e, t & 3, true);           // |byte| < 2^8, dequantiser < 2^14; stored as int16
+        prod = svb > 0 ? 0 : prod;
+        *(lds_i16_t*)(my_a + (e & 0xFFFFu)) = (int16_t)prod;
+        ca = med3_i32(ca + 4, (svb << 2) + ca, ca_end);        // == min(ca + 4 * max(1, svb), end) below the end
+      };
+      // DC (unsigned; 0xFF was handled above) or raw byte t, 1 <= t <= bt8 (signed): slot t
+      auto raw = [&](int t) {
+        const uint32_t e = *(const lds_u32_t*)(tab_a + 4u * (uint32_t)t);
+        *(lds_i16_t*)(my_a + (uint32_t)slot_byte(t)) = (int16_t)mul_byte_hi16(wd[t >> 2], e, t & 3, t != 0);
+      };
+      // first 16 bytes; B8 >= 0: bt8 known at compile time
+      bool more = true;
+      auto first_round = [&](auto b8c) {
+        constexpr int B8 = decltype(b8c)::value;
+#pragma unroll
+        for (int t = 0; t < 16; t++) {
+          if (t == 8) {
+            ca = min(ca, ca_end);
+            more = __any(ca < ca_end);
+            if (!more) break;
+          }
+          if (B8 >= 0 ? t <= B8 : t <= (int)bt8) raw(t);
+          else token(t);
+        }
+        if (more) {
+          ca = min(ca, ca_end);
+          more = __any(ca < ca_end);
+        }
+      };
+      switch (bt8) {
+        case 9: first_round(std::integral_constant<int, 9>{}); break;
+        case 8: first_round(std::integral_constant<int, 8>{}); break;
+        case 4: first_round(std::integral_constant<int, 4>{}); break;
+        case 0: first_round(std::integral_constant<int, 0>{}); break;
+        default: first_round(std::integral_constant<int, -1>{}); break;
+      }
       uint32_t pnext = pos0;
-      while (true) {
-        const uint32_t wd[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
-                                __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
-        // 16 bytes are in registers; they are consumed eight at a time so that short blocks stop early
-        // (here luma blocks are 13..24 bytes, chroma 2..5)
-        bool more = true;
+      while (more) {
+        pnext += 16u;
+        const Bytes nb = fetch(pnext, inside);  // same alignment as pos0: nb.d[0] is the old d4
+        wd[0] = __builtin_amdgcn_alignbyte(nb.d[1], nb.d[0], sh);
+        wd[1] = __builtin_amdgcn_alignbyte(nb.d[2], nb.d[1], sh);
+        wd[2] = __builtin_amdgcn_alignbyte(nb.d[3], nb.d[2], sh);
+        wd[3] = __builtin_amdgcn_alignbyte(nb.d[4], nb.d[3], sh);
 #pragma unroll
         for (int half = 0; half < 2; half++) {
           if (more) {
 #pragma unroll
-            for (int t = 8 * half; t < 8 * half + 8; t++) {
-              const uint32_t j = jbase + t;
-              const uint32_t ub = (wd[t >> 2] >> (8 * (t & 3))) & 0xFFu;
-              const int sv = (int)(int8_t)ub;
-              const int val = j == 0u ? (int)ub : sv;                // DC is the only unsigned byte
-              const bool run = j > bt8 && sv > 63;                   // zero run of sv-63 slots (scratch is already 0)
-              const bool live = co < 64u;
-              const uint32_t e = tab[co & 63u];
-              const int prod = mul24(val, (int)(e >> 8));            // |val| < 2^8, dequantiser < 2^15
-              my[(live && !run) ? (e & 63u) : 64u] = (int16_t)prod;  // slot 64 is a write-only dump
-              co += run ? (uint32_t)(sv - 63) : 1u;
-            }
-            more = __any(co < 64u);
+            for (int t = 8 * half; t < 8 * half + 8; t++) token(t);
+            ca = min(ca, ca_end);
+            more = __any(ca < ca_end);
           }
         }
-        if (!more) break;
-        jbase += 16u;
-        pnext += 16u;
-        const Bytes nb = fetch(pnext);  // same alignment as pos0: nb.d[0] is the old d4
-        d0 = nb.d[0];
-        d1 = nb.d[1];
-        d2 = nb.d[2];
-        d3 = nb.d[3];
-        d4 = nb.d[4];
       }
     }
 
     // ---- request the next group's stream bytes: they arrive while this group is transformed ----
     Bytes nxt;
-    if (have_n) nxt = fetch(pos_n);
+    bool inside_n = false;
+    if (have_n) {
+      inside_n = __all(pos_n + kFetchSpan <= f.data_len);
+      nxt = fetch(pos_n, inside_n);
+    }
+
+    // ---- does any block of the wave reach outside the low 4x4?  (columns 4-7, rows 4-7) ----
+    bool lo = false;
+    if (try_lo) {  // wave-uniform
+      uint32_t hi = 0;
+      if (live_blk) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const uint2 q = *(const uint2*)((const uint8_t*)my + 16 * c + 8);
+          hi |= q.x | q.y;
+        }
+#pragma unroll
+        for (int c = 4; c < 8; c++) {
+          const uint4 q = my[c];
+          hi |= q.x | q.y | q.z | q.w;
+        }
+      }
+      lo = !__any(hi != 0u);
+      try_lo = lo;
+    }
 
     if (live_blk) {
-      // ---- column pass: column c of the block is the c-th 16-byte piece of the scratch ----
-      int ws[8][8];
-#pragma unroll
-      for (int c = 0; c < 8; c++) {
-        const uint4 q = ((const uint4*)my)[c];
-        int x0 = (int)(int16_t)(q.x & 0xFFFFu), x1 = (int)q.x >> 16;
-        const int x2 = (int)(int16_t)(q.y & 0xFFFFu), x3 = (int)q.y >> 16;
-        const int x4 = (int)(int16_t)(q.z & 0xFFFFu), x5 = (int)q.z >> 16;
-        const int x6 = (int)(int16_t)(q.w & 0xFFFFu), x7 = (int)q.w >> 16;
-        if (c == 0) x0 += 4;  // DESCALE's rounding term, carried through both linear DC paths
-        int y[8];
-        idct8(x0, x1, x2, x3, x4, x5, x6, x7, y);
-#pragma unroll
-        for (int r = 0; r < 8; r++) ws[r][c] = y[r];
-      }
-
-      // ---- row pass + scatter ----
       // macroblock coordinates without a per-lane division: one scalar division for the group's
       // first macroblock, then at most one row wrap per lane when rows are at least a group wide
       uint32_t mx, my_;
@@ -384,15 +527,57 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
         const size_t ysz = (size_t)f.w * f.h;
         dst = outbuf + f.out_off + ysz + (kblk == 5u ? ysz >> 2 : 0) + (size_t)(8u * my_) * stride + 8u * mx;
       }
-#pragma unroll
-      for (int r = 0; r < 8; r++) {
-        int y[8];
-        idct8(ws[r][0], ws[r][1], ws[r][2], ws[r][3], ws[r][4], ws[r][5], ws[r][6], ws[r][7], y);
+      auto put_row = [&](const int (&y)[8]) {
         uint2 o;
         o.x = px(y[0]) | (px(y[1]) << 8) | (px(y[2]) << 16) | (px(y[3]) << 24);
         o.y = px(y[4]) | (px(y[5]) << 8) | (px(y[6]) << 16) | (px(y[7]) << 24);
         *(uint2*)dst = o;
         dst += stride;
+      };
+
+      if (lo) {
+        // ---- four-input transform: columns 0-3 in, rows of four in ----
+        int ws[8][4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const uint2 q = *(const uint2*)((const uint8_t*)my + 16 * c);
+          int x0 = (int)(int16_t)(q.x & 0xFFFFu);
+          const int x1 = (int)q.x >> 16, x2 = (int)(int16_t)(q.y & 0xFFFFu), x3 = (int)q.y >> 16;
+          if (c == 0) x0 += 4;  // DESCALE's rounding term, carried through both linear DC paths
+          int y[8];
+          idct8_lo(x0, x1, x2, x3, y);
+#pragma unroll
+          for (int r = 0; r < 8; r++) ws[r][c] = y[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          int y[8];
+          idct8_lo(ws[r][0], ws[r][1], ws[r][2], ws[r][3], y);
+          put_row(y);
+        }
+      } else {
+        // ---- column pass: column c of the block is the c-th 16-byte piece of the scratch ----
+        int ws[8][8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          const uint4 q = my[c];
+          int x0 = (int)(int16_t)(q.x & 0xFFFFu), x1 = (int)q.x >> 16;
+          const int x2 = (int)(int16_t)(q.y & 0xFFFFu), x3 = (int)q.y >> 16;
+          const int x4 = (int)(int16_t)(q.z & 0xFFFFu), x5 = (int)q.z >> 16;
+          const int x6 = (int)(int16_t)(q.w & 0xFFFFu), x7 = (int)q.w >> 16;
+          if (c == 0) x0 += 4;  // DESCALE's rounding term, carried through both linear DC paths
+          int y[8];
+          idct8(x0, x1, x2, x3, x4, x5, x6, x7, y);
+#pragma unroll
+          for (int r = 0; r < 8; r++) ws[r][c] = y[r];
+        }
+        // ---- row pass + scatter ----
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          int y[8];
+          idct8(ws[r][0], ws[r][1], ws[r][2], ws[r][3], ws[r][4], ws[r][5], ws[r][6], ws[r][7], y);
+          put_row(y);
+        }
       }
     }
     if (!have_n) break;
@@ -401,6 +586,7 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
     valid = valid_n;
     pos0 = pos_n;
     cur = nxt;
+    inside = inside_n;
   }
 }
 

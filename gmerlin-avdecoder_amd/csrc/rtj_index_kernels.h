@@ -57,11 +57,17 @@ __device__ __forceinline__ void search_lengths(const uint16_t* s_w, const uint8_
 #pragma unroll
         for (int t = 0; t < NT; t++) {
           const uint32_t w = *(const uint16_t*)((const uint8_t*)s_w + addr[u][t] + 2 * step);
-          // "still below" = bit 15 of the difference (the sums differ by < 2^15 and are kept mod 2^16);
-          // spelled as bit-field extract + shift-add: three instructions per step instead of four
-          const uint32_t below = __builtin_amdgcn_ubfe(w - tgt[u][t], 15, 1);
-          uint32_t na;
-          asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(na) : "v"(below), "n"(__builtin_ctz(2 * step)), "v"(addr[u][t]));
+          // "still below" = bit 15 of the difference (the sums differ by < 2^15 and are kept mod 2^16).
+          // Three instructions per step; the 16-bit subtract and the plain shift are in the VALU's
+          // fast class (~2.5 cycles a wave, profiles/r01 valu_kinds), a bit-field extract is not (~4.3)
+          uint32_t dlt, na;
+#ifdef MIRTJ_SEARCH_BFE
+          dlt = __builtin_amdgcn_ubfe(w - tgt[u][t], 15, 1);
+#else
+          asm("v_sub_u16 %0, %1, %2" : "=v"(dlt) : "v"(w), "v"(tgt[u][t]));
+          asm("v_lshrrev_b32 %0, 15, %1" : "=v"(dlt) : "v"(dlt));
+#endif
+          asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(na) : "v"(dlt), "n"(__builtin_ctz(2 * step)), "v"(addr[u][t]));
           addr[u][t] = na;
         }
       }
