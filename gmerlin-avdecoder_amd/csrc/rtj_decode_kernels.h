@@ -314,7 +314,10 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
                                                          const uint32_t* __restrict__ blkoff,
                                                          uint8_t* __restrict__ outbuf) {
   constexpr int kCoefWords = kDecThreads * kCoefStride / 2;
-  __shared__ __attribute__((aligned(16))) uint32_t s_lds[kCoefWords + kSlotTabN];
+#ifndef MIRTJ_DEC_LDS_PAD
+#define MIRTJ_DEC_LDS_PAD 0
+#endif
+  __shared__ __attribute__((aligned(16))) uint32_t s_lds[kCoefWords + kSlotTabN + MIRTJ_DEC_LDS_PAD];
   uint32_t* s_tab = s_lds + kCoefWords;  // per zig-zag slot: (dequantiser << 16) | scratch byte offset
 
   const FrameDev f = frames[blockIdx.y];

@@ -32,6 +32,9 @@ constexpr int kSumThreads = 256;
 #define MIRTJ_SEARCH_UNROLL 8
 #endif
 constexpr int kSearchUnroll = MIRTJ_SEARCH_UNROLL;
+#ifndef MIRTJ_SUM_WAVES
+#define MIRTJ_SUM_WAVES 7
+#endif
 
 // Block length at every table position for NT (1 or 2) distinct block types; see step 3 of
 // k_index_summarize for the method.
@@ -92,7 +95,7 @@ __device__ __forceinline__ void search_lengths(const uint16_t* s_w, const uint8_
 }
 
 template <int NT>
-__global__ __launch_bounds__(kSumThreads, 5) void k_index_summarize(const FrameDev* __restrict__ frames,
+__global__ __launch_bounds__(kSumThreads, MIRTJ_SUM_WAVES) void k_index_summarize(const FrameDev* __restrict__ frames,
                                                                   const uint8_t* __restrict__ stream,
                                                                   const QTab* __restrict__ lut,
                                                                   uint32_t* __restrict__ summary,
@@ -101,12 +104,22 @@ __global__ __launch_bounds__(kSumThreads, 5) void k_index_summarize(const FrameD
   __shared__ __attribute__((aligned(16))) uint16_t s_w[kStageN];       // inclusive weight sums mod 2^16
   __shared__ __attribute__((aligned(16))) uint8_t s_nl[kTabN];         // block length if luma ...
   __shared__ __attribute__((aligned(16))) uint8_t s_nc[kTabN];         // ... or chroma
-  __shared__ uint16_t s_f[kChunk];                                     // macroblock length
   __shared__ uint32_t s_wave[kSumThreads / 64];
-  __shared__ uint16_t s_slot[2 * kEntries];  // first-hop targets: marker, then index into s_list
-  __shared__ uint16_t s_list[kEntries];      // the distinct first-hop targets
-  __shared__ uint32_t s_res[kEntries];       // (macroblocks << 16) | exit offset of each distinct target
   __shared__ uint32_t s_grp[12];
+#ifdef MIRTJ_SUM_NOALIAS
+  __shared__ uint16_t s_f[kChunk];
+  __shared__ uint16_t s_slot[2 * kEntries];
+  __shared__ uint16_t s_list[kEntries];
+  __shared__ uint32_t s_res[kEntries];
+#else
+  // the sums and the bytes are dead once the lengths are known (step 3): their space is reused, which
+  // brings the workgroup to 20 KB of LDS, i.e. up to eight workgroups per CU instead of five
+  static_assert(kChunk <= kStageN && 2 * kEntries + kEntries + 2 * kEntries <= kStageN / 2, "aliased LDS layout");
+  uint16_t* const s_f = s_w;                               // macroblock length
+  uint16_t* const s_slot = (uint16_t*)s_b4;                // first-hop targets: marker, then index into s_list
+  uint16_t* const s_list = s_slot + 2 * kEntries;          // the distinct first-hop targets
+  uint32_t* const s_res = (uint32_t*)(s_list + kEntries);  // (macroblocks << 16) | exit offset of each distinct target
+#endif
 
   const FrameDev f = frames[blockIdx.y];
   const uint32_t c = blockIdx.x;

@@ -4,7 +4,7 @@
 set -u
 cd "$(dirname "$0")/.."
 mkdir -p gmerlin-avdecoder_amd/lib/ab
-declare -A V=( [base]="" [bfe]="-DMIRTJ_SEARCH_BFE" )
+declare -A V=( [base]="" )
 if [ "${1:-build}" = build ]; then
   for k in "${!V[@]}"; do
     MI_RTJ_CFLAGS="${V[$k]}" python -c "
