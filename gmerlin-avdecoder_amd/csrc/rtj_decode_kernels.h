@@ -354,28 +354,31 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
   // the dword that holds stream byte `p` and the four after it, bytes at or past data_len read as 0;
   // `inside`: every lane's loads are known to lie inside the packet
   struct Bytes {
-    uint32_t d[5];
+    uint32_t d[9];
   };
-  auto fetch = [&](uint32_t p, bool inside) -> Bytes {
+  auto fetch = [&](uint32_t p, bool inside, int n) -> Bytes {
     const uint8_t* g = data + p;
     const uint32_t sh = (uint32_t)((uintptr_t)g & 3u);
     const uint32_t* g4 = (const uint32_t*)(g - sh);
     Bytes b;
     if (inside) {
 #pragma unroll
-      for (int k = 0; k < 5; k++) b.d[k] = g4[k];
+      for (int k = 0; k < 9; k++)
+        if (k < n) b.d[k] = g4[k];
       return b;
     }
     const long long rel = (long long)p - (long long)sh;  // position of g4[0]'s first byte
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-      const long long rem = (long long)f.data_len - (rel + 4ll * k);
-      uint32_t v = 0;
-      if (rem > 0) {
-        v = g4[k];
-        if (rem < 4) v &= (1u << (8 * (int)rem)) - 1u;
+    for (int k = 0; k < 9; k++) {
+      if (k < n) {
+        const long long rem = (long long)f.data_len - (rel + 4ll * k);
+        uint32_t v = 0;
+        if (rem > 0) {
+          v = g4[k];
+          if (rem < 4) v &= (1u << (8 * (int)rem)) - 1u;
+        }
+        b.d[k] = v;
       }
-      b.d[k] = v;
     }
     return b;
   };
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
   bool valid = mb < f.nmb;
   uint32_t pos0 = valid ? off[6u * mb + kblk] : 0u;  // block start relative to the first data byte
   bool inside = __all(pos0 + kFetchSpan <= f.data_len);  // wave-uniform
-  Bytes cur = fetch(pos0, inside);
+  Bytes cur = fetch(pos0, inside, 9);  // 32 bytes (+ alignment): all of most blocks
   bool try_lo = true;  // wave-uniform: test this wave's blocks for "low 4x4 only" until a test fails
 
   for (int it = 0; it < kDecIters; it++) {
@@ -415,39 +418,49 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
                         __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
       int ca = (int)tab_a + 4 * ((int)bt8 + 1);  // DC and the raw bytes have their slots fixed
 
-      // a token: one coefficient, or (64..127) a run of sv-63 zero slots (lib/RTjpeg.c:171-182)
-      auto token = [&](int t) {
-        const uint32_t w = wd[t >> 2];
-        const int svb = sbyte_minus(w, t & 3, k63);            // token - 63: > 0 for a run, its length
-        const uint32_t e = *(const lds_u32_t*)(uint32_t)ca;
-        int prod = mul_byte_hi16(w, e, t & 3, true);           // |byte| < 2^8, dequantiser < 2^14; stored as int16
-        prod = svb > 0 ? 0 : prod;
-        *(lds_i16_t*)(my_a + (e & 0xFFFFu)) = (int16_t)prod;
-        ca = med3_i32(ca + 4, (svb << 2) + ca, ca_end);        // == min(ca + 4 * max(1, svb), end) below the end
-      };
-      // DC (unsigned; 0xFF was handled above) or raw byte t, 1 <= t <= bt8 (signed): slot t
-      auto raw = [&](int t) {
-        const uint32_t e = *(const lds_u32_t*)(tab_a + 4u * (uint32_t)t);
-        *(lds_i16_t*)(my_a + (uint32_t)slot_byte(t)) = (int16_t)mul_byte_hi16(wd[t >> 2], e, t & 3, t != 0);
+      // Eight bytes t0..t0+7 of the current 16.  A token is one coefficient or (64..127) a run of
+      // token-63 zero slots (lib/RTjpeg.c:171-182); DC (unsigned; 0xFF was handled above) and raw byte t,
+      // 1 <= t <= bt8 (signed), sit at slot t.  The slot counter only depends on the bytes, so all
+      // eight table reads are issued before the first product is needed.
+      auto half_round = [&](int t0, auto b8c, bool first) {
+        constexpr int B8 = decltype(b8c)::value;
+        int svb[8];
+        uint32_t e[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int t = t0 + k;
+          const uint32_t w = wd[t >> 2];
+          const bool is_raw = first && (B8 >= 0 ? t <= B8 : t <= (int)bt8);
+          if (is_raw) {
+            e[k] = *(const lds_u32_t*)(tab_a + 4u * (uint32_t)t);
+            svb[k] = 0;
+          } else {
+            svb[k] = sbyte_minus(w, t & 3, k63);  // token - 63: > 0 for a run, its length
+            e[k] = *(const lds_u32_t*)(uint32_t)ca;
+            ca = med3_i32(ca + 4, (svb[k] << 2) + ca, ca_end);  // == min(ca + 4 * max(1, svb), end) below the end
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int t = t0 + k;
+          const uint32_t w = wd[t >> 2];
+          const bool is_raw = first && (B8 >= 0 ? t <= B8 : t <= (int)bt8);
+          if (is_raw) {
+            *(lds_i16_t*)(my_a + (uint32_t)slot_byte(t)) = (int16_t)mul_byte_hi16(w, e[k], t & 3, t != 0);
+          } else {
+            int prod = mul_byte_hi16(w, e[k], t & 3, true);  // |byte| < 2^8, dequantiser < 2^14; stored as int16
+            prod = svb[k] > 0 ? 0 : prod;
+            *(lds_i16_t*)(my_a + (e[k] & 0xFFFFu)) = (int16_t)prod;
+          }
+        }
+        ca = min(ca, ca_end);
+        return (bool)__any(ca < ca_end);
       };
       // first 16 bytes; B8 >= 0: bt8 known at compile time
       bool more = true;
       auto first_round = [&](auto b8c) {
-        constexpr int B8 = decltype(b8c)::value;
-#pragma unroll
-        for (int t = 0; t < 16; t++) {
-          if (t == 8) {
-            ca = min(ca, ca_end);
-            more = __any(ca < ca_end);
-            if (!more) break;
-          }
-          if (B8 >= 0 ? t <= B8 : t <= (int)bt8) raw(t);
-          else token(t);
-        }
-        if (more) {
-          ca = min(ca, ca_end);
-          more = __any(ca < ca_end);
-        }
+        more = half_round(0, b8c, true);
+        if (more) more = half_round(8, b8c, true);
       };
       switch (bt8) {
         case 9: first_round(std::integral_constant<int, 9>{}); break;
@@ -456,23 +469,25 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
         case 0: first_round(std::integral_constant<int, 0>{}); break;
         default: first_round(std::integral_constant<int, -1>{}); break;
       }
-      uint32_t pnext = pos0;
-      while (more) {
+      if (more) {
+        // bytes 16..31 are in registers already
+        wd[0] = __builtin_amdgcn_alignbyte(cur.d[5], d4, sh);
+        wd[1] = __builtin_amdgcn_alignbyte(cur.d[6], cur.d[5], sh);
+        wd[2] = __builtin_amdgcn_alignbyte(cur.d[7], cur.d[6], sh);
+        wd[3] = __builtin_amdgcn_alignbyte(cur.d[8], cur.d[7], sh);
+        more = half_round(0, std::integral_constant<int, -1>{}, false);
+        if (more) more = half_round(8, std::integral_constant<int, -1>{}, false);
+      }
+      uint32_t pnext = pos0 + 16u;
+      while (more) {  // blocks longer than 32 bytes: fetched on demand
         pnext += 16u;
-        const Bytes nb = fetch(pnext, inside);  // same alignment as pos0: nb.d[0] is the old d4
+        const Bytes nb = fetch(pnext, inside, 5);  // same alignment as pos0
         wd[0] = __builtin_amdgcn_alignbyte(nb.d[1], nb.d[0], sh);
         wd[1] = __builtin_amdgcn_alignbyte(nb.d[2], nb.d[1], sh);
         wd[2] = __builtin_amdgcn_alignbyte(nb.d[3], nb.d[2], sh);
         wd[3] = __builtin_amdgcn_alignbyte(nb.d[4], nb.d[3], sh);
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-          if (more) {
-#pragma unroll
-            for (int t = 8 * half; t < 8 * half + 8; t++) token(t);
-            ca = min(ca, ca_end);
-            more = __any(ca < ca_end);
-          }
-        }
+        more = half_round(0, std::integral_constant<int, -1>{}, false);
+        if (more) more = half_round(8, std::integral_constant<int, -1>{}, false);
       }
     }
 
@@ -481,7 +496,7 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
     bool inside_n = false;
     if (have_n) {
       inside_n = __all(pos_n + kFetchSpan <= f.data_len);
-      nxt = fetch(pos_n, inside_n);
+      nxt = fetch(pos_n, inside_n, 9);
     }
 
     // ---- does any block of the wave reach outside the low 4x4?  (columns 4-7, rows 4-7) ----
