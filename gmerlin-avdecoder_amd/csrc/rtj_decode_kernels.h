@@ -268,7 +268,7 @@ constexpr int kDecThreads = 64;
 #define MIRTJ_DEC_WAVES 1
 #endif
 #ifndef MIRTJ_DEC_ITERS
-#define MIRTJ_DEC_ITERS 4
+#define MIRTJ_DEC_ITERS 3
 #endif
 constexpr int kCoefStride = MIRTJ_COEF_STRIDE;  // int16 per lane: 64 + 8 pad (144 B, conflict-free b128 reads)
 constexpr int kDecIters = MIRTJ_DEC_ITERS;      // macroblock groups a wave works through, one after the other
