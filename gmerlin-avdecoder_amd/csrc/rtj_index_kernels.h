@@ -32,66 +32,116 @@ constexpr int kSumThreads = 256;
 #define MIRTJ_SEARCH_UNROLL 8
 #endif
 constexpr int kSearchUnroll = MIRTJ_SEARCH_UNROLL;
+#ifndef MIRTJ_F_CHAINS
+#define MIRTJ_F_CHAINS 7
+#endif
 #ifndef MIRTJ_SUM_WAVES
 #define MIRTJ_SUM_WAVES 7
 #endif
 
-// Block length at every table position for NT (1 or 2) distinct block types; see step 3 of
-// k_index_summarize for the method.
+// One search step: probe `step` entries ahead; still below the target -> move on by `step`.
+// "Below" = bit 15 of the difference (the sums differ by < 2^15 and are kept mod 2^16).  Three
+// instructions: 16-bit subtract, shift, shift-add into the byte address; the probe distance is an
+// immediate offset of the LDS read.
+template <int STEP>
+__device__ __forceinline__ uint32_t search_step(const uint16_t* s_w, uint32_t addr, uint32_t tgt) {
+  const uint32_t w = *(const uint16_t*)((const uint8_t*)s_w + addr + 2 * STEP);
+  uint32_t dlt, na;
+  asm("v_sub_u16 %0, %1, %2" : "=v"(dlt) : "v"(w), "v"(tgt));
+  asm("v_lshrrev_b32 %0, 15, %1" : "=v"(dlt) : "v"(dlt));
+  asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(na) : "v"(dlt), "n"(__builtin_ctz(2 * STEP)), "v"(addr));
+  return na;
+}
+
+// Block length at every table position: s_nl[i] = length of a luma block that starts at i, s_nc[i] = of
+// a chroma block (separate byte arrays: four positions to a bank keeps the macroblock chase's scattered
+// reads mostly conflict-free; interleaving the two was measured slower).  A block of a type with bt8 raw bytes that starts at i has its
+// last raw byte at p = i + bt8 and ends at p + d, d the smallest distance with W[p + d] >= W[p] + need,
+// need = 63 - bt8.  d - 1 is built bit by bit (32, 16, .. 1); searching the full 1..64 window is exact
+// because the predicate is monotone.
+//   NT == 1 (lb8 == cb8, two thirds of the qualities): one search per position serves both types.
+//   NT == 2: the searches are organised by p, not by i.  From one p the type with MORE raw bytes
+//   needs FEWER slots, so its end comes first (six steps); the other type needs bA - bB <= 15 slots
+//   more, every byte covers at least one, so its end is at most 15 bytes further: four more steps
+//   from where the first search stopped.  Ten steps for both instead of twelve; the two results
+//   belong to different start positions (p - bA and p - bB).
+// kSearchUnroll positions are searched together so that their dependent reads overlap.
+// A first byte 0xFF (block of length 1) is patched in afterwards by patch_unchanged_blocks.
 template <int NT>
-__device__ __forceinline__ void search_lengths(const uint16_t* s_w, const uint8_t* s_b, uint8_t* s_nl, uint8_t* s_nc,
-                                               uint32_t lb8, uint32_t cb8, int tid) {
-  const uint32_t bt8v[2] = {lb8, cb8}, needv[2] = {63u - lb8, 63u - cb8};
-  for (int i0 = tid; i0 < kTabN; i0 += kSumThreads * kSearchUnroll) {
-    uint32_t addr[kSearchUnroll][NT], tgt[kSearchUnroll][NT];
+__device__ __forceinline__ void search_lengths(const uint16_t* s_w, uint8_t* s_nl, uint8_t* s_nc, uint32_t lb8, uint32_t cb8, int tid) {
+  const bool luma_first = lb8 >= cb8;
+  const uint32_t bA = luma_first ? lb8 : cb8, bB = luma_first ? cb8 : lb8;  // bA >= bB
+  uint8_t* const s_a = luma_first ? s_nl : s_nc;  // lengths of the type searched first / second
+  uint8_t* const s_b2 = luma_first ? s_nc : s_nl;
+  const int np = kTabN + (NT == 2 ? (int)bA : 0);  // NT == 1: p runs over the start positions themselves
+  for (int p0 = tid; p0 < np; p0 += kSumThreads * kSearchUnroll) {
+    uint32_t addr[kSearchUnroll], tgt[kSearchUnroll];
 #pragma unroll
     for (int u = 0; u < kSearchUnroll; u++) {
-      const uint32_t i = (uint32_t)min(i0 + u * kSumThreads, kTabN - 1);
-#pragma unroll
-      for (int t = 0; t < NT; t++) {
-        addr[u][t] = 2u * (i + bt8v[t]);  // byte address of W[iq]
-        tgt[u][t] = (uint32_t)s_w[i + bt8v[t]] + needv[t];
-      }
+      const uint32_t p = (uint32_t)min(p0 + u * kSumThreads, np - 1) + (NT == 1 ? bA : 0u);
+      addr[u] = 2u * p;  // byte address of W[p]
+      tgt[u] = (uint32_t)s_w[p] + (63u - bA);
     }
 #pragma unroll
-    for (int step = 32; step >= 1; step >>= 1) {
+    for (int u = 0; u < kSearchUnroll; u++) addr[u] = search_step<32>(s_w, addr[u], tgt[u]);
+#pragma unroll
+    for (int u = 0; u < kSearchUnroll; u++) addr[u] = search_step<16>(s_w, addr[u], tgt[u]);
+#pragma unroll
+    for (int u = 0; u < kSearchUnroll; u++) addr[u] = search_step<8>(s_w, addr[u], tgt[u]);
+#pragma unroll
+    for (int u = 0; u < kSearchUnroll; u++) addr[u] = search_step<4>(s_w, addr[u], tgt[u]);
+#pragma unroll
+    for (int u = 0; u < kSearchUnroll; u++) addr[u] = search_step<2>(s_w, addr[u], tgt[u]);
+#pragma unroll
+    for (int u = 0; u < kSearchUnroll; u++) addr[u] = search_step<1>(s_w, addr[u], tgt[u]);
+    if (NT == 1) {
 #pragma unroll
       for (int u = 0; u < kSearchUnroll; u++) {
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-          const uint32_t w = *(const uint16_t*)((const uint8_t*)s_w + addr[u][t] + 2 * step);
-          // "still below" = bit 15 of the difference (the sums differ by < 2^15 and are kept mod 2^16).
-          // Three instructions per step; the 16-bit subtract and the plain shift are in the VALU's
-          // fast class (~2.5 cycles a wave, profiles/r01 valu_kinds), a bit-field extract is not (~4.3)
-          uint32_t dlt, na;
-#ifdef MIRTJ_SEARCH_BFE
-          dlt = __builtin_amdgcn_ubfe(w - tgt[u][t], 15, 1);
-#else
-          asm("v_sub_u16 %0, %1, %2" : "=v"(dlt) : "v"(w), "v"(tgt[u][t]));
-          asm("v_lshrrev_b32 %0, 15, %1" : "=v"(dlt) : "v"(dlt));
-#endif
-          asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(na) : "v"(dlt), "n"(__builtin_ctz(2 * step)), "v"(addr[u][t]));
-          addr[u][t] = na;
+        const int i = p0 + u * kSumThreads;
+        if (i < kTabN) {
+          const uint32_t len = addr[u] / 2u + 2u - (uint32_t)i;  // last byte is W index addr/2 + 1
+          s_nl[i] = (uint8_t)len;
+          s_nc[i] = (uint8_t)len;
         }
       }
-    }
+    } else {
 #pragma unroll
-    for (int u = 0; u < kSearchUnroll; u++) {
-      const int i = i0 + u * kSumThreads;
-      if (i < kTabN) {
-        uint32_t len[2];
+      for (int u = 0; u < kSearchUnroll; u++) {
+        const int p = p0 + u * kSumThreads;
+        if (p < np && p >= (int)bA) s_a[p - (int)bA] = (uint8_t)(addr[u] / 2u + 2u - (uint32_t)(p - (int)bA));
+        tgt[u] += bA - bB;
+      }
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
-          const uint32_t e = addr[u][t] / 2u + 1u;  // index of the block's last byte
-          len[t] = needv[t] ? e + 1u - (uint32_t)i : 64u;
-        }
-        if (NT == 1) len[1] = len[0];
-        if (s_b[i] == 0xFFu) len[0] = len[1] = 1u;
-        s_nl[i] = (uint8_t)len[0];
-        s_nc[i] = (uint8_t)len[1];
+      for (int u = 0; u < kSearchUnroll; u++) addr[u] = search_step<8>(s_w, addr[u], tgt[u]);
+#pragma unroll
+      for (int u = 0; u < kSearchUnroll; u++) addr[u] = search_step<4>(s_w, addr[u], tgt[u]);
+#pragma unroll
+      for (int u = 0; u < kSearchUnroll; u++) addr[u] = search_step<2>(s_w, addr[u], tgt[u]);
+#pragma unroll
+      for (int u = 0; u < kSearchUnroll; u++) addr[u] = search_step<1>(s_w, addr[u], tgt[u]);
+#pragma unroll
+      for (int u = 0; u < kSearchUnroll; u++) {
+        const int p = p0 + u * kSumThreads, i = p - (int)bB;
+        if (p < np && i >= 0 && i < kTabN) s_b2[i] = (uint8_t)(addr[u] / 2u + 2u - (uint32_t)i);
       }
     }
   }
+}
+
+// A block whose first byte is 0xFF is one byte long whatever its type (lib/RTjpeg.c:2704).  Rare (only
+// streams with unchanged blocks have them), so it is patched in after the search: every thread looks
+// at 16 bytes at once.
+__device__ __forceinline__ void patch_unchanged_blocks(const uint32_t* s_b4, uint8_t* s_nl, uint8_t* s_nc, int tid) {
+  if (16 * tid >= kTabN) return;
+  const uint4 q = ((const uint4*)s_b4)[tid];
+  const uint32_t d[4] = {q.x, q.y, q.z, q.w};
+  uint32_t any = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) any |= (~d[k] - 0x01010101u) & d[k] & 0x80808080u;  // a byte of ~d is zero
+  if (any == 0u) return;
+#pragma unroll
+  for (int k = 0; k < 16; k++)
+    if (((d[k >> 2] >> (8 * (k & 3))) & 0xFFu) == 0xFFu) s_nl[16 * tid + k] = s_nc[16 * tid + k] = 1;
 }
 
 template <int NT>
@@ -135,17 +185,23 @@ __global__ __launch_bounds__(kSumThreads, MIRTJ_SUM_WAVES) void k_index_summariz
     const uint32_t* g4 = (const uint32_t*)(g - mis);
     // bytes of the packet left from the chunk start on (plans keep data_len below 2^31)
     const uint32_t left = f.data_len > cbase ? f.data_len - cbase : 0u;
-    for (int j = tid; j < kStageN / 4; j += kSumThreads) {
-      // LDS dword j = stream bytes cbase+4j .. +3 = aligned global dwords j, j+1 shifted by mis;
-      // g4[j] starts mis bytes before chunk byte 4j
-      const uint32_t b = 4u * (uint32_t)j;
-      uint32_t lo = 0, hi = 0;
-      if (b < left + mis) lo = g4[j];
-      if (mis && b + 4u < left + mis) hi = g4[j + 1];
-      uint32_t v = mis ? __builtin_amdgcn_alignbyte(hi, lo, mis) : lo;
-      if (b >= left) v = 0;
-      else if (left - b < 4u) v &= (1u << (8u * (left - b))) - 1u;
-      s_b4[j] = v;
+    if (left >= (uint32_t)kStageN + 4u) {
+      // the whole window (and the dword after it) lies inside the packet: all chunks but a packet's last two
+      for (int j = tid; j < kStageN / 4; j += kSumThreads)
+        s_b4[j] = __builtin_amdgcn_alignbyte(g4[j + 1], g4[j], mis);  // mis is uniform: a funnel shift by 0 is a copy
+    } else {
+      for (int j = tid; j < kStageN / 4; j += kSumThreads) {
+        // LDS dword j = stream bytes cbase+4j .. +3 = aligned global dwords j, j+1 shifted by mis;
+        // g4[j] starts mis bytes before chunk byte 4j
+        const uint32_t b = 4u * (uint32_t)j;
+        uint32_t lo = 0, hi = 0;
+        if (b < left + mis) lo = g4[j];
+        if (mis && b + 4u < left + mis) hi = g4[j + 1];
+        uint32_t v = mis ? __builtin_amdgcn_alignbyte(hi, lo, mis) : lo;
+        if (b >= left) v = 0;
+        else if (left - b < 4u) v &= (1u << (8u * (left - b))) - 1u;
+        s_b4[j] = v;
+      }
     }
   }
   __syncthreads();
@@ -158,7 +214,8 @@ __global__ __launch_bounds__(kSumThreads, MIRTJ_SUM_WAVES) void k_index_summariz
     uint32_t run = 0;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-      run += token_weight((d[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+      // token_weight(b) == max((int8)b - 63, 1): the byte select and sign extension ride on the subtract
+      run += (uint32_t)max(sbyte_minus(d[i >> 2], i & 3, 63), 1);
       loc[i] = run;
     }
     const uint32_t incl = wave_incl_scan(run);
@@ -168,24 +225,19 @@ __global__ __launch_bounds__(kSumThreads, MIRTJ_SUM_WAVES) void k_index_summariz
     for (int k = 0; k < wv; k++) off += s_wave[k];
     uint32_t pk[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) pk[i] = ((loc[2 * i] + off) & 0xFFFFu) | ((loc[2 * i + 1] + off) << 16);
+    for (int i = 0; i < 8; i++) pk[i] = __builtin_amdgcn_perm(loc[2 * i + 1] + off, loc[2 * i] + off, 0x05040100u);  // low halves
     uint4* dst = (uint4*)(s_w + 16 * tid);
     dst[0] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
     dst[1] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
   }
   __syncthreads();
 
-  // ---- 3. block length at every position, for both block types ----
-  // A block that starts at i has its last raw byte at iq = i + bt8 and ends at iq + d, d the
-  // smallest distance with W[iq + d] >= W[iq] + need.  d - 1 is built bit by bit (32, 16, .. 1): the
-  // probe distance is an immediate offset of the LDS read, so a step is three vector instructions
-  // (subtract, extract the "still below" bit, shift-add it into the byte address).  Searching the
-  // full 1..64 window is exact for any need <= 63 because the predicate is monotone.
-  // kSearchUnroll positions x 2 types are searched together so that their dependent reads overlap.
+  // ---- 3. block length at every position, for both block types (see search_lengths) ----
   const uint32_t lb8 = (uint32_t)lut[f.qidx].lb8, cb8 = (uint32_t)lut[f.qidx].cb8;
-  // NT == 1: every packet of the launch has lb8 == cb8 (true for two thirds of the qualities, Q below
-  // ~171), so one search serves both block types; the host picks the instantiation per plan.
-  search_lengths<NT>(s_w, s_b, s_nl, s_nc, lb8, cb8, tid);
+  // the host picks the instantiation per plan: NT == 1 when every packet of the launch has lb8 == cb8
+  search_lengths<NT>(s_w, s_nl, s_nc, lb8, cb8, tid);
+  __syncthreads();
+  patch_unchanged_blocks(s_b4, s_nl, s_nc, tid);
   __syncthreads();
 
   // both lengths of the chunk's own positions go to HBM for k_index_emit: (luma | chroma << 8)
@@ -203,16 +255,26 @@ __global__ __launch_bounds__(kSumThreads, MIRTJ_SUM_WAVES) void k_index_summariz
   }
 
   // ---- 4. macroblock length: four luma blocks then two chroma blocks ----
-  for (int p = tid; p < kChunk; p += kSumThreads) {
-    uint32_t q = p;
-    asm volatile("" : "+v"(q));  // one register for the position: each lookup is a read and an add
-    q += s_nl[q];
-    q += s_nl[q];
-    q += s_nl[q];
-    q += s_nl[q];
-    q += s_nc[q];
-    q += s_nc[q];
-    s_f[p] = (uint16_t)(q - p);
+  // kFChains positions per thread are chased together: the six lookups of one position depend on each
+  // other, those of different positions do not
+  {
+    constexpr int kFChains = MIRTJ_F_CHAINS;
+    static_assert(kChunk % (kSumThreads * kFChains) == 0, "macroblock-length pass covers the chunk in whole rounds");
+    for (int p0 = tid; p0 < kChunk; p0 += kSumThreads * kFChains) {
+      uint32_t q[kFChains];
+#pragma unroll
+      for (int u = 0; u < kFChains; u++) q[u] = (uint32_t)(p0 + u * kSumThreads);
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        uint32_t l[kFChains];
+#pragma unroll
+        for (int u = 0; u < kFChains; u++) l[u] = k < 4 ? s_nl[q[u]] : s_nc[q[u]];
+#pragma unroll
+        for (int u = 0; u < kFChains; u++) q[u] += l[u];
+      }
+#pragma unroll
+      for (int u = 0; u < kFChains; u++) s_f[p0 + u * kSumThreads] = (uint16_t)(q[u] - (uint32_t)(p0 + u * kSumThreads));
+    }
   }
   __syncthreads();
   // ---- 5. every possible entry offset walked to the end of the chunk ----

@@ -13,7 +13,7 @@ b=importlib.import_module('gmerlin-avdecoder_amd.build'); print(b.build(force=Tr
   done
 else
   for rep in 1 2; do for k in "${!V[@]}"; do
-    MI_RTJ_LIB=$PWD/gmerlin-avdecoder_amd/lib/ab/lib_$k.so python bench.py --no-cpu 2>/dev/null | python -c "
+    MI_RTJ_LIB=$PWD/gmerlin-avdecoder_amd/lib/ab/lib_$k.so timeout -k 10 120 python bench.py --no-cpu 2>/dev/null | python -c "
 import sys,json; d=json.loads(sys.stdin.read()); print('$k', d['value'], {a:b['ms'] for a,b in d['kernels'].items()})"
   done; done
 fi
