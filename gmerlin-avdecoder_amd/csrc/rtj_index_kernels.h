@@ -442,20 +442,30 @@ __global__ __launch_bounds__(kEmitThreads) void k_index_emit(const FrameDev* __r
   }
   __syncthreads();
 
-  // ---- macroblock length at every position: six dependent reads, four positions chased together ----
-  for (int p0 = tid; p0 < kChunk; p0 += 4 * kEmitThreads) {
-    uint32_t q[4];
+  // ---- macroblock length at every position: six dependent reads, kEmitChains positions chased together.
+  //      The position is kept as a byte address into s_len (luma length at +0, chroma at +1), so that a
+  //      step is one byte read and one shift-add ----
+  {
+    constexpr int kEmitChains = 7;
+    static_assert(kChunk % (kEmitThreads * kEmitChains) == 0 || kEmitThreads != 256, "whole rounds");
+    const uint8_t* lb = (const uint8_t*)s_len;
+    for (int p0 = tid; p0 < kChunk; p0 += kEmitChains * kEmitThreads) {
+      uint32_t q[kEmitChains];
 #pragma unroll
-    for (int u = 0; u < 4; u++) q[u] = min(p0 + u * kEmitThreads, kChunk - 1);
+      for (int u = 0; u < kEmitChains; u++) q[u] = 2u * (uint32_t)min(p0 + u * kEmitThreads, kChunk - 1);
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
+      for (int k = 0; k < 6; k++) {
+        uint32_t l[kEmitChains];
 #pragma unroll
-      for (int u = 0; u < 4; u++) q[u] += k < 4 ? (s_len[q[u]] & 0xFFu) : (s_len[q[u]] >> 8);
-    }
+        for (int u = 0; u < kEmitChains; u++) l[u] = lb[q[u] + (k < 4 ? 0u : 1u)];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int p = p0 + u * kEmitThreads;
-      if (p < kChunk) s_f[p] = (uint16_t)(q[u] - p);
+        for (int u = 0; u < kEmitChains; u++) q[u] += 2u * l[u];
+      }
+#pragma unroll
+      for (int u = 0; u < kEmitChains; u++) {
+        const int p = p0 + u * kEmitThreads;
+        if (p < kChunk) s_f[p] = (uint16_t)(q[u] / 2u - (uint32_t)p);
+      }
     }
   }
   __syncthreads();
