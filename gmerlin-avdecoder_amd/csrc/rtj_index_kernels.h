@@ -347,12 +347,28 @@ __global__ __launch_bounds__(256) void k_index_resolve(const FrameDev* __restric
     s_state[0] = 0;  // entry offset into the current chunk
     s_state[1] = 0;  // macroblocks before it
   }
+  // the next tile's summaries are requested into registers before the current tile is chained, so
+  // that their latency hides behind the serial part
+  constexpr int kPer = kResTile * kEntries / 256;
+  static_assert(kPer * 256 == kResTile * kEntries, "tile is a whole number of rounds");
+  uint32_t pre[kPer];
+  auto request = [&](uint32_t c0) {
+    const uint32_t nt = min((uint32_t)kResTile, f.nchunks - c0);
+    const uint32_t* src = summary + (size_t)(f.sum_base + c0) * kEntries;
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+      const uint32_t i = (uint32_t)tid + 256u * (uint32_t)k;
+      pre[k] = i < nt * kEntries ? src[i] : 0u;
+    }
+  };
+  if (f.nchunks) request(0);
   for (uint32_t c0 = 0; c0 < f.nchunks; c0 += kResTile) {
     const uint32_t nt = min((uint32_t)kResTile, f.nchunks - c0);
     __syncthreads();
-    const uint32_t* src = summary + (size_t)(f.sum_base + c0) * kEntries;
-    for (uint32_t i = tid; i < nt * kEntries; i += 256) s_sum[i] = src[i];
+#pragma unroll
+    for (int k = 0; k < kPer; k++) s_sum[tid + 256 * k] = pre[k];
     __syncthreads();
+    if (c0 + kResTile < f.nchunks) request(c0 + kResTile);
     if (tid == 0) {
       uint32_t e = s_state[0], mb = s_state[1];
       for (uint32_t j = 0; j < nt; j++) {
