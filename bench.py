@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=256, help="distinct frames resident per GPU")
+    ap.add_argument("--frames", type=int, default=1024, help="distinct frames resident per GPU")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1088)
     ap.add_argument("--quality", type=int, default=255)
@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--seed", type=int, default=12345)
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="also time one reference decoder per host core of this process's share (extra field)")
     ap.add_argument("--no-verify", action="store_true")
     return ap.parse_args()
 
@@ -89,6 +91,23 @@ def cpu_baseline(pkts, w, h, budget_s, gpu_planes):
             "sample": f"{done} frames of the same {w}x{h} packets, decode + one frame copy, {dt:.1f} s, "
                       f"host has {os.cpu_count()} logical cores",
             "mpixels_per_s": round(done * w * h / dt / 1e6, 1)}, mismatches
+
+
+def _cpu_worker(args):
+    pkts, w, h, budget_s = args
+    return cpu_baseline(pkts, w, h, budget_s, {})[0]["value"]
+
+
+def cpu_baseline_all_cores(pkts, w, h, budget_s):
+    """One reference decoder per core this process may use (one stream each, as independent bgav instances
+    would run): the honest "whole host share" figure of SURVEY.md section 8d."""
+    import multiprocessing as mp
+    cores = len(os.sched_getaffinity(0))
+    with mp.get_context("spawn").Pool(cores) as pool:
+        vals = pool.map(_cpu_worker, [(pkts[: min(len(pkts), 8)], w, h, budget_s)] * cores)
+    return {"value": round(sum(vals), 1), "unit": "frames/s", "cores": cores, "kind": "reference"
+            if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "librtjpeg_ref.so")) else "port",
+            "sample": f"{cores} processes, one decoder each, {budget_s:.0f} s, same packets"}
 
 
 def main():
@@ -177,7 +196,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                tj = json.load(open(tpath))  # PMC bytes per launch of tj["frames_per_launch"] frames; linear in frames
+                traffic = int(tj[dom] * n / tj.get("frames_per_launch", 256)) if dom in tj else None
             except Exception:
                 traffic = None
         # the north star's kernel of interest, whatever dominates: IDCT + plane scatter
@@ -211,6 +231,12 @@ def main():
             out["cpu_baseline"] = cb
             out["parity_mismatches"] = mism
             out["speedup_vs_cpu_1core"] = round(fps / cb["value"], 1)
+            if a.cpu_all_cores:
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(pkts, w, h, a.cpu_seconds)
+        # what a plain streaming copy kernel sustains on this device (read + write), measured now: the second
+        # yardstick of SURVEY.md section 8d next to the nominal peak (last: it overwrites half of the output)
+        half = (fsz * n // 2) & ~15
+        out["copy_ceiling_gbs"] = round(dev.copy_ceiling(d_out, d_out + half, half), 1)
         print(json.dumps(out), flush=True)
 
     plan.close()

@@ -28,7 +28,8 @@ EXPORTS = ["mi_rtj_device_count", "mi_rtj_create", "mi_rtj_destroy", "mi_rtj_las
            "mi_rtj_dev_memset", "mi_rtj_sync", "mi_rtj_plan_create", "mi_rtj_plan_destroy",
            "mi_rtj_plan_decode", "mi_rtj_plan_info", "mi_rtj_plan_profile", "mi_rtj_plan_times",
            "mi_rtj_plan_read_index", "mi_rtj_synth_frames", "mi_rtj_encode_bound", "mi_rtj_encode_frames",
-           "mi_rtj_get_tables", "mi_rtj_yuv420_to_rgb", "mi_rtj_encode_stream", "mi_rtj_decode_nocopy"]
+           "mi_rtj_get_tables", "mi_rtj_yuv420_to_rgb", "mi_rtj_encode_stream", "mi_rtj_decode_nocopy",
+           "mi_rtj_copy_ceiling"]
 
 
 KERNELS = ("k_index_summarize", "k_index_resolve", "k_index_emit", "k_decode")
@@ -76,6 +77,7 @@ def load():
     L.mi_rtj_encode_stream.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp,
                                        C.c_int, u64p, u32p]
     L.mi_rtj_get_tables.argtypes = [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.mi_rtj_copy_ceiling.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
     _LIB = L
     return L
 
@@ -255,6 +257,12 @@ class MiRtj:
     # -- colour stage (N2) --
     def to_rgb(self, fmt, w, h, n, d_planes, in_stride, d_rgb, row_pitch, out_stride):
         self._chk(self.L.mi_rtj_yuv420_to_rgb(self.h, fmt, w, h, n, d_planes, in_stride, d_rgb, row_pitch, out_stride))
+
+    def copy_ceiling(self, d_src, d_dst, nbytes, reps=10):
+        """GB/s (read + write) a plain streaming copy kernel sustains on this device."""
+        g = C.c_double()
+        self._chk(self.L.mi_rtj_copy_ceiling(self.h, d_src, d_dst, nbytes, reps, C.byref(g)))
+        return g.value
 
     # -- generator side --
     def synth(self, w, h, first, n, seed=12345, amp=8, dptr=None):

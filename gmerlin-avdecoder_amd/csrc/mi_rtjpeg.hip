@@ -755,6 +755,29 @@ int mi_rtj_yuv420_to_rgb(mi_rtj_ctx* c, int fmt, int w, int h, int n, const void
   return MI_RTJ_OK;
 }
 
+int mi_rtj_copy_ceiling(mi_rtj_ctx* c, const void* d_src, void* d_dst, size_t bytes, int reps, double* gbs) {
+  if (!c || !d_src || !d_dst || !gbs || bytes < 16 || (bytes & 15) || reps < 1 || ((uintptr_t)d_src & 15) || ((uintptr_t)d_dst & 15))
+    return fail(c, MI_RTJ_ERR_ARG, "mi_rtj_copy_ceiling: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0));
+  HIPCHK(c, hipEventCreate(&e1));
+  const size_t n16 = bytes / 16;
+  const unsigned grid = (unsigned)std::min<size_t>((n16 + 255) / 256, 256u * 32u);
+  hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, c->stream, (const uint4*)d_src, (uint4*)d_dst, n16);  // warm-up
+  HIPCHK(c, hipEventRecord(e0, c->stream));
+  for (int r = 0; r < reps; r++)
+    hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, c->stream, (const uint4*)d_src, (uint4*)d_dst, n16);
+  HIPCHK(c, hipEventRecord(e1, c->stream));
+  HIPCHK(c, hipEventSynchronize(e1));
+  float ms = 0;
+  HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  *gbs = 2.0 * (double)bytes * reps / ((double)ms * 1e6);
+  return MI_RTJ_OK;
+}
+
 int mi_rtj_get_tables(int Q, int32_t tables[128], int* lb8, int* cb8) {
   if (!tables || Q < 1 || Q > 255) return MI_RTJ_ERR_ARG;
   QTab t;

@@ -99,4 +99,9 @@ __global__ __launch_bounds__(256) void k_yuv420_to_rgb(const uint8_t* __restrict
   }
 }
 
+// plain streaming copy, 16 bytes per lane: the yardstick for what a pure HBM-bound kernel sustains
+__global__ __launch_bounds__(256) void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 }  // namespace mirtj

@@ -138,6 +138,12 @@ enum { MI_RTJ_RGB32 = 0, MI_RTJ_BGR32 = 1, MI_RTJ_RGB24 = 2, MI_RTJ_BGR24 = 3, M
 int mi_rtj_yuv420_to_rgb(mi_rtj_ctx *ctx, int fmt, int w, int h, int n, const void *d_planes,
                          size_t in_frame_stride, void *d_rgb, size_t row_pitch, size_t out_frame_stride);
 
+/* Measurement aid (SURVEY.md §8d "achievable-copy ceiling"): copies `bytes` (a multiple of 16) from d_src to
+ * d_dst `reps` times with a plain 16-byte-per-lane grid-stride kernel and returns the sustained
+ * read+write rate in GB/s in *gbs — the HBM rate a pure streaming kernel reaches on this device, the
+ * second yardstick next to the nominal 8 TB/s.  Synchronous. */
+int mi_rtj_copy_ceiling(mi_rtj_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, int reps, double *gbs);
+
 /* Dequantiser tables the device uses for quality Q (1..255): 64 luma + 64 chroma entries in
  * natural order and the lb8/cb8 counts — the values RTjpeg_get_tables returns
  * (lib/RTjpeg.c:2371-2378) after RTjpeg_set_quality. */

@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from a tools/pmc_summary.py summary: HBM bytes per launch of every kernel.
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM section;
+checked on k_index_emit, which streams the length table: 301 MB + 10.7 % halo = 333 MB, counter 166 MB)."""
+import json, sys
+src, dst, tag, frames = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+d = json.load(open(src))
+out = {"note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes "
+               "(tools/pmc_passes.sh), state %s; FETCH_SIZE doubled per the gfx950 correction" % tag, "kernels": {}}
+for k, v in d.items():
+    if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+        continue
+    r, w = int(v["FETCH_SIZE"] * 1024 * 2), int(v["WRITE_SIZE"] * 1024)
+    out["kernels"][k] = {"hbm_read_bytes": r, "hbm_write_bytes": w, "hbm_bytes": r + w}
+out["frames_per_launch"] = frames  # bench.py scales the figures to its own batch (traffic is linear in frames)
+for k, v in out["kernels"].items():
+    out[k] = v["hbm_bytes"]
+json.dump(out, open(dst, "w"), indent=1)
