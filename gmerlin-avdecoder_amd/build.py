@@ -44,5 +44,26 @@ def build(force=False, verbose=False, out=None):
     return out or LIB
 
 
+TEST_VARIANT = os.path.join(LIBDIR, "libmi_rtjpeg_generic_paths.so")
+
+
+def build_test_variant(force=False):
+    """The same library compiled with -DMIRTJ_TEST_GENERIC_PATHS: the kernels always take the paths
+    that real tables and whole packets rarely reach (run-time raw-byte count in the parse loop, masked
+    loads near a packet's end).  Loaded only by tests/test_gpu_variant_paths.py."""
+    if not force and os.path.exists(TEST_VARIANT) and \
+            all(os.path.getmtime(f) <= os.path.getmtime(TEST_VARIANT) for f in _deps()):
+        return TEST_VARIANT
+    old = os.environ.get("MI_RTJ_CFLAGS")
+    os.environ["MI_RTJ_CFLAGS"] = ((old + " ") if old else "") + "-DMIRTJ_TEST_GENERIC_PATHS"
+    try:
+        return build(force=True, out=TEST_VARIANT)
+    finally:
+        if old is None:
+            del os.environ["MI_RTJ_CFLAGS"]
+        else:
+            os.environ["MI_RTJ_CFLAGS"] = old
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

@@ -274,6 +274,11 @@ constexpr int kCoefStride = MIRTJ_COEF_STRIDE;  // int16 per lane: 64 + 8 pad (1
 constexpr int kDecIters = MIRTJ_DEC_ITERS;      // macroblock groups a wave works through, one after the other
 constexpr int kSlotTabN = 64 + 16;              // slot table: 64 coefficient slots, then "block finished" entries
 constexpr int kMaxRawBytes = 15;                // the host refuses tables with more leading 8-bit coefficients
+#ifdef MIRTJ_TEST_GENERIC_PATHS  // test build: always take the paths real tables and whole packets rarely reach
+constexpr bool kForceGenericPaths = true;
+#else
+constexpr bool kForceGenericPaths = false;
+#endif
 constexpr uint32_t kFetchSpan = 72;             // a block's loads stay below its start + this (64 + alignment + look-ahead)
 
 // ---------------------------------------------------------------------------------------
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
   uint32_t mb = grp * (uint32_t)kMbPerGroup + dmb;
   bool valid = mb < f.nmb;
   uint32_t pos0 = valid ? off[6u * mb + kblk] : 0u;  // block start relative to the first data byte
-  bool inside = __all(pos0 + kFetchSpan <= f.data_len);  // wave-uniform
+  bool inside = !kForceGenericPaths && __all(pos0 + kFetchSpan <= f.data_len);  // wave-uniform
   Bytes cur = fetch(pos0, inside, 9);  // 32 bytes (+ alignment): all of most blocks
   bool try_lo = true;  // wave-uniform: test this wave's blocks for "low 4x4 only" until a test fails
 
@@ -462,7 +467,7 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
         more = half_round(0, b8c, true);
         if (more) more = half_round(8, b8c, true);
       };
-      switch (bt8) {
+      switch (kForceGenericPaths ? 99u : bt8) {
         case 9: first_round(std::integral_constant<int, 9>{}); break;
         case 8: first_round(std::integral_constant<int, 8>{}); break;
         case 4: first_round(std::integral_constant<int, 4>{}); break;
@@ -495,7 +500,7 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
     Bytes nxt;
     bool inside_n = false;
     if (have_n) {
-      inside_n = __all(pos_n + kFetchSpan <= f.data_len);
+      inside_n = !kForceGenericPaths && __all(pos_n + kFetchSpan <= f.data_len);
       nxt = fetch(pos_n, inside_n, 9);
     }
 

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kSumThreads, MIRTJ_SUM_WAVES) void k_index_summariz
     const uint32_t* g4 = (const uint32_t*)(g - mis);
     // bytes of the packet left from the chunk start on (plans keep data_len below 2^31)
     const uint32_t left = f.data_len > cbase ? f.data_len - cbase : 0u;
-    if (left >= (uint32_t)kStageN + 4u) {
+    if (!kForceGenericPaths && left >= (uint32_t)kStageN + 4u) {
       // the whole window (and the dword after it) lies inside the packet: all chunks but a packet's last two
       for (int j = tid; j < kStageN / 4; j += kSumThreads)
         s_b4[j] = __builtin_amdgcn_alignbyte(g4[j + 1], g4[j], mis);  // mis is uniform: a funnel shift by 0 is a copy

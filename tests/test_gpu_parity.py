@@ -334,6 +334,80 @@ def test_fuzz_arbitrary_bytes(dev):
         assert first_diff(got, want) is None, (i, first_diff(got, want))
 
 
+def _packet_from_blocks(w, h, Q, blocks):
+    body = b"".join(bytes(b) for b in blocks)
+    total = 12 + len(body)
+    hdr = bytes([total & 255, (total >> 8) & 255, (total >> 16) & 255, (total >> 24) & 255, 12, 0,
+                 w & 255, w >> 8, h & 255, h >> 8, Q, 0])
+    return np.frombuffer(hdr + body, dtype=np.uint8).copy()
+
+
+def test_low_4x4_transform_path_and_its_boundary(dev):
+    """k_decode runs a four-input transform when no block of a wave has a coefficient outside the low
+    4x4.  Packets are built so that whole waves qualify, whole waves do not, a wave stops qualifying from
+    one macroblock group to the next, and the single coefficient sits on every one of the 63 AC slots
+    (inside, on the edge of and outside the 4x4) with values where the int16 narrowing shows."""
+    rng = np.random.default_rng(99)
+    pkts = []
+    for Q in (255, 200, 150, 3):
+        _, _, lb8, cb8, _, _ = R.oracle_tables(Q)
+        for (w, h, mode) in ((512, 64, "one"), (1024, 32, "flat_then_busy"), (512, 32, "dc_only")):
+            nmb = (w // 16) * (h // 16)
+            blocks = []
+            for mb in range(nmb):
+                for k in range(6):
+                    bt8 = lb8 if k < 4 else cb8
+                    blk = [int(rng.integers(0, 255))] + [0] * bt8  # DC, raw bytes zero unless chosen below
+                    if mode == "one":
+                        slot = 1 + (mb * 6 + k) % 63          # the one AC coefficient: every slot in turn
+                    elif mode == "flat_then_busy":
+                        slot = int(rng.integers(1, 4)) if mb < nmb // 2 else int(rng.integers(1, 64))
+                    else:
+                        slot = 0
+                    val = int(rng.integers(-128, 64)) & 0xFF if slot else 0
+                    if slot and slot <= bt8:
+                        blk[slot] = val
+                        blk.append(63 + 63 - bt8)             # one run over all token slots
+                    elif slot:
+                        before = slot - bt8 - 1
+                        if before:
+                            blk.append(63 + before)
+                        blk.append(val if val < 64 or val > 127 else 1)
+                        after = 63 - slot
+                        if after:
+                            blk.append(63 + after)
+                    else:
+                        blk.append(63 + 63 - bt8)
+                    blocks.append(blk)
+            pkts.append(_packet_from_blocks(w, h, Q, blocks))
+    outs = batch_decode(dev, pkts, prefill=0x33)
+    dec = R.OracleDecoder()
+    for i, (p, got) in enumerate(zip(pkts, outs)):
+        w, h = int(p[6]) | (int(p[7]) << 8), int(p[8]) | (int(p[9]) << 8)
+        want = np.full(frame_bytes(w, h), 0x33, np.uint8)
+        dec.decode(p, want)
+        assert first_diff(got, want) is None, (i, first_diff(got, want))
+
+
+@pytest.mark.parametrize("w,h,Q", [(320, 240, 255), (1920, 1088, 255), (640, 368, 128), (320, 240, 20)])
+def test_flat_and_half_flat_content(dev, w, h, Q):
+    """Encoder-made streams whose luma waves take the low-4x4 path (flat gradient), do not (noise), and
+    pictures that are flat on the left and noisy on the right."""
+    flat = R.synth_frame(w, h, 0, amp=0)
+    noisy = R.synth_frame(w, h, 1, amp=40)
+    half = flat.copy()
+    y = half[: w * h].reshape(h, w)
+    y[:, w // 2:] = noisy[: w * h].reshape(h, w)[:, w // 2:]
+    enc = R.OracleEncoder(w, h, Q)
+    pkts = [enc.encode(f) for f in (flat, half, noisy, flat)]
+    outs = batch_decode(dev, pkts)
+    dec = R.OracleDecoder()
+    for i, (p, got) in enumerate(zip(pkts, outs)):
+        want = np.zeros(frame_bytes(w, h), np.uint8)
+        dec.decode(p, want)
+        assert first_diff(got, want) is None, (i, first_diff(got, want))
+
+
 # --------------------------------------------------------------------------- generator side (N1)
 @pytest.mark.parametrize("w,h,amp", [(64, 48, 8), (320, 240, 64), (1920, 1088, 8)])
 def test_synth_matches_numpy_twin(dev, w, h, amp):
