@@ -29,10 +29,11 @@ EXPORTS = ["mi_rtj_device_count", "mi_rtj_create", "mi_rtj_destroy", "mi_rtj_las
            "mi_rtj_plan_decode", "mi_rtj_plan_info", "mi_rtj_plan_profile", "mi_rtj_plan_times",
            "mi_rtj_plan_read_index", "mi_rtj_synth_frames", "mi_rtj_encode_bound", "mi_rtj_encode_frames",
            "mi_rtj_get_tables", "mi_rtj_yuv420_to_rgb", "mi_rtj_encode_stream", "mi_rtj_decode_nocopy",
-           "mi_rtj_copy_ceiling"]
+           "mi_rtj_copy_ceiling", "mi_rtj_plan_spec_stats"]
 
 
-KERNELS = ("k_index_summarize", "k_index_resolve", "k_index_emit", "k_decode")
+KERNELS = ("k_index_summarize", "k_index_resolve", "k_index_emit", "k_decode", "k_spec_walk", "k_spec_verify",
+           "k_spec_expand")
 
 
 def load():
@@ -67,6 +68,7 @@ def load():
     L.mi_rtj_plan_info.argtypes = [vp, C.POINTER(C.c_int), u64p, u64p, u64p]
     L.mi_rtj_plan_profile.argtypes = [vp, C.c_int]
     L.mi_rtj_plan_times.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    L.mi_rtj_plan_spec_stats.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
     L.mi_rtj_plan_read_index.argtypes = [vp, u32p, C.c_size_t]
     L.mi_rtj_synth_frames.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, vp]
     L.mi_rtj_encode_bound.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
@@ -122,8 +124,14 @@ class Plan:
     def profile(self, on=True):
         self.owner.L.mi_rtj_plan_profile(self.h, 1 if on else 0)
 
+    def spec_stats(self):
+        """(packets proven by the speculative index in the last decode, stream chunks it covered; 0 = unused)."""
+        pr, wk = C.c_int(), C.c_longlong()
+        self.owner._chk(self.owner.L.mi_rtj_plan_spec_stats(self.h, C.byref(pr), C.byref(wk)))
+        return pr.value, wk.value
+
     def times(self):
-        ms = (C.c_float * 4)()
+        ms = (C.c_float * len(KERNELS))()
         n = C.c_int()
         self.owner._chk(self.owner.L.mi_rtj_plan_times(self.h, ms, C.byref(n)))
         return dict(zip(KERNELS, [float(x) for x in ms])), n.value

@@ -17,6 +17,7 @@
 #include "rtj_decode_kernels.h"
 #include "rtj_encode_kernels.h"
 #include "rtj_index_kernels.h"
+#include "rtj_spec_kernels.h"
 #include "rtj_tables.h"
 
 using namespace mirtj;
@@ -69,6 +70,19 @@ struct mi_rtj_plan {
   bool serial_index = false;        // MI_RTJ_INDEX=serial: one wave per packet (A/B baseline)
   bool emit_walk = false;           // MI_RTJ_EMIT=walk: per-chunk re-walk instead of the length tables
   bool one_block_type = false;      // every frame's tables have lb8 == cb8: single-search summarize
+  // speculative index (rtj_spec_kernels.h): one walker per kSpecChunk bytes, proven per packet afterwards
+  int spec_mode = -1;               // MI_RTJ_SPEC: 0 never, 1 always, otherwise by batch size
+  bool spec = false;
+  uint64_t n_spec = 0, cap_spec = 0;       // walkers of this plan / allocated
+  std::vector<SpecChunkDev> h_spec_chunks;
+  std::vector<uint32_t> h_spec_base;       // [n + 1]
+  SpecChunkDev* d_spec_chunks = nullptr;
+  uint32_t* d_spec_base = nullptr;
+  uint16_t* d_spec_rec = nullptr;          // [walkers][kSpecCap]
+  uint32_t* d_spec_nrec = nullptr;
+  SpecInfoDev* d_spec_info = nullptr;
+  uint32_t* d_spec_ok = nullptr;           // [n]: 1 = the packet's index is proven, the exact kernels skip it
+  int cap_spec_frames = 0;
   std::vector<Timed> ev[MI_RTJ_NUM_KERNELS];  // one pair per launch while profiling
   int launches = 0;
 };
@@ -176,6 +190,53 @@ int plan_alloc_chunks(mi_rtj_plan* p) {
     HIPCHK(c, hipMalloc((void**)&p->d_chunk_mb, sizeof(uint32_t) * entries));
     p->n_chunk_entries = entries;
   }
+  // ---- speculative index: worth it once the batch fills the device (a walker is one lane and runs
+  //      for ~0.25 ms whatever the batch; a single packet is indexed faster by the exact kernels) ----
+  uint64_t walkers = 0;
+  for (auto& f : p->h_frames) walkers += f.data_len ? (f.data_len + kSpecChunk - 1) / kSpecChunk : 1;
+  p->spec = !p->serial_index && !p->emit_walk && (p->spec_mode == 1 || (p->spec_mode != 0 && walkers >= kSpecMinWalkers));
+  if (p->spec) {
+    p->h_spec_chunks.clear();
+    p->h_spec_base.assign(1, 0u);
+    for (size_t i = 0; i < p->h_frames.size(); i++) {
+      const FrameDev& f = p->h_frames[i];
+      const uint32_t nsc = f.data_len ? (f.data_len + kSpecChunk - 1) / kSpecChunk : 1;
+      for (uint32_t k = 0; k < nsc; k++) p->h_spec_chunks.push_back(SpecChunkDev{(uint32_t)i, k});
+      p->h_spec_base.push_back((uint32_t)p->h_spec_chunks.size());
+    }
+    p->n_spec = p->h_spec_chunks.size();
+    if ((p->n_spec + 1) * (uint64_t)kSpecCap * 2 >= 0xFFFFFFFFull) p->spec = false;  // record offsets are 32-bit
+  }
+  if (p->spec) {
+    if (p->n_spec > p->cap_spec) {
+      if (p->d_spec_chunks) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(p->d_spec_chunks);
+        (void)hipFree(p->d_spec_rec);
+        (void)hipFree(p->d_spec_nrec);
+        (void)hipFree(p->d_spec_info);
+        p->d_spec_chunks = nullptr;
+      }
+      HIPCHK(c, hipMalloc((void**)&p->d_spec_chunks, sizeof(SpecChunkDev) * p->n_spec));
+      HIPCHK(c, hipMalloc((void**)&p->d_spec_rec, sizeof(uint16_t) * kSpecCap * (p->n_spec + 1)));  // + a spare row for idle lanes
+      HIPCHK(c, hipMalloc((void**)&p->d_spec_nrec, sizeof(uint32_t) * p->n_spec));
+      HIPCHK(c, hipMalloc((void**)&p->d_spec_info, sizeof(SpecInfoDev) * p->n_spec));
+      p->cap_spec = p->n_spec;
+    }
+    if ((int)p->h_frames.size() > p->cap_spec_frames) {
+      if (p->d_spec_base) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(p->d_spec_base);
+        (void)hipFree(p->d_spec_ok);
+      }
+      HIPCHK(c, hipMalloc((void**)&p->d_spec_base, sizeof(uint32_t) * (p->h_frames.size() + 1)));
+      HIPCHK(c, hipMalloc((void**)&p->d_spec_ok, sizeof(uint32_t) * p->h_frames.size()));
+      p->cap_spec_frames = (int)p->h_frames.size();
+    }
+    HIPCHK(c, hipMemcpyAsync(p->d_spec_chunks, p->h_spec_chunks.data(), sizeof(SpecChunkDev) * p->n_spec, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(p->d_spec_base, p->h_spec_base.data(), sizeof(uint32_t) * p->h_spec_base.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // the host vectors may be rebuilt by the next call
+  }
   return MI_RTJ_OK;
 }
 
@@ -210,17 +271,33 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
     hipLaunchKernelGGL(k_index_walk, dim3(p->n), dim3(64), 0, c->stream, p->d_frames, st, c->d_lut, p->d_blkoff);
     if ((rc = end(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
   } else {
+    const uint32_t* ok = nullptr;
+    if (p->spec) {
+      ok = p->d_spec_ok;
+      if ((rc = begin(MI_RTJ_K_SPEC_WALK)) != MI_RTJ_OK) return rc;
+      hipLaunchKernelGGL(k_spec_walk, dim3((unsigned)((p->n_spec + 63) / 64)), dim3(64), 0, c->stream, p->d_frames,
+                         p->d_spec_chunks, (uint32_t)p->n_spec, st, c->d_lut, p->d_spec_rec, p->d_spec_nrec);
+      if ((rc = end(MI_RTJ_K_SPEC_WALK)) != MI_RTJ_OK) return rc;
+      if ((rc = begin(MI_RTJ_K_SPEC_VERIFY)) != MI_RTJ_OK) return rc;
+      hipLaunchKernelGGL(k_spec_verify, dim3(p->n), dim3(256), 0, c->stream, p->d_frames, p->d_spec_base, c->d_lut,
+                         p->d_spec_rec, p->d_spec_nrec, p->d_spec_info, p->d_spec_ok);
+      if ((rc = end(MI_RTJ_K_SPEC_VERIFY)) != MI_RTJ_OK) return rc;
+      if ((rc = begin(MI_RTJ_K_SPEC_EXPAND)) != MI_RTJ_OK) return rc;
+      hipLaunchKernelGGL(k_spec_expand, dim3((unsigned)p->n_spec), dim3(64), 0, c->stream, p->d_frames,
+                         p->d_spec_chunks, p->d_spec_rec, p->d_spec_info, p->d_spec_ok, p->d_blkoff);
+      if ((rc = end(MI_RTJ_K_SPEC_EXPAND)) != MI_RTJ_OK) return rc;
+    }
     if ((rc = begin(MI_RTJ_K_SUMMARIZE)) != MI_RTJ_OK) return rc;
     if (p->one_block_type)
       hipLaunchKernelGGL(k_index_summarize<1>, dim3(p->max_chunks, p->n), dim3(kSumThreads), 0, c->stream, p->d_frames,
-                         st, c->d_lut, p->d_summary, p->d_lentab);
+                         st, c->d_lut, p->d_summary, p->d_lentab, ok);
     else
       hipLaunchKernelGGL(k_index_summarize<2>, dim3(p->max_chunks, p->n), dim3(kSumThreads), 0, c->stream, p->d_frames,
-                         st, c->d_lut, p->d_summary, p->d_lentab);
+                         st, c->d_lut, p->d_summary, p->d_lentab, ok);
     if ((rc = end(MI_RTJ_K_SUMMARIZE)) != MI_RTJ_OK) return rc;
     if ((rc = begin(MI_RTJ_K_RESOLVE)) != MI_RTJ_OK) return rc;
     hipLaunchKernelGGL(k_index_resolve, dim3(p->n), dim3(256), 0, c->stream, p->d_frames, p->d_summary,
-                       p->d_chunk_pos, p->d_chunk_mb);
+                       p->d_chunk_pos, p->d_chunk_mb, ok);
     if ((rc = end(MI_RTJ_K_RESOLVE)) != MI_RTJ_OK) return rc;
     if ((rc = begin(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
     if (p->emit_walk)
@@ -228,7 +305,7 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
                          c->d_lut, p->d_chunk_pos, p->d_chunk_mb, p->d_blkoff);
     else
       hipLaunchKernelGGL(k_index_emit, dim3(p->max_chunks, p->n), dim3(kEmitThreads), 0, c->stream, p->d_frames,
-                         p->d_lentab, p->d_chunk_pos, p->d_chunk_mb, p->d_blkoff);
+                         p->d_lentab, p->d_chunk_pos, p->d_chunk_mb, p->d_blkoff, ok);
     if ((rc = end(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
   }
   if ((rc = begin(MI_RTJ_K_DECODE)) != MI_RTJ_OK) return rc;
@@ -423,6 +500,8 @@ mi_rtj_plan* mi_rtj_plan_create(mi_rtj_ctx* c, int n, const uint8_t* headers, co
     p->serial_index = mode && strcmp(mode, "serial") == 0;
     const char* em = getenv("MI_RTJ_EMIT");
     p->emit_walk = em && strcmp(em, "walk") == 0;
+    const char* sp = getenv("MI_RTJ_SPEC");
+    p->spec_mode = sp ? atoi(sp) : -1;
   }
   if (hipSetDevice(c->device) != hipSuccess || plan_alloc_chunks(p) != MI_RTJ_OK) {
     mi_rtj_plan_destroy(p);
@@ -452,6 +531,12 @@ void mi_rtj_plan_destroy(mi_rtj_plan* p) {
   if (p->d_lentab) (void)hipFree(p->d_lentab);
   if (p->d_chunk_pos) (void)hipFree(p->d_chunk_pos);
   if (p->d_chunk_mb) (void)hipFree(p->d_chunk_mb);
+  if (p->d_spec_chunks) (void)hipFree(p->d_spec_chunks);
+  if (p->d_spec_base) (void)hipFree(p->d_spec_base);
+  if (p->d_spec_rec) (void)hipFree(p->d_spec_rec);
+  if (p->d_spec_nrec) (void)hipFree(p->d_spec_nrec);
+  if (p->d_spec_info) (void)hipFree(p->d_spec_info);
+  if (p->d_spec_ok) (void)hipFree(p->d_spec_ok);
   delete p;
 }
 
@@ -490,6 +575,20 @@ int mi_rtj_plan_times(mi_rtj_plan* p, float ms[MI_RTJ_NUM_KERNELS], int* launche
     }
   }
   if (launches) *launches = (int)p->ev[MI_RTJ_K_DECODE].size();
+  return MI_RTJ_OK;
+}
+
+int mi_rtj_plan_spec_stats(mi_rtj_plan* p, int* proven, long long* walkers) {
+  if (!p || !proven || !walkers) return MI_RTJ_ERR_ARG;
+  mi_rtj_ctx* c = p->ctx;
+  *proven = 0;
+  *walkers = p->spec ? (long long)p->n_spec : 0;
+  if (!p->spec) return MI_RTJ_OK;
+  std::vector<uint32_t> ok(p->n);
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(ok.data(), p->d_spec_ok, sizeof(uint32_t) * p->n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (uint32_t v : ok) *proven += v ? 1 : 0;
   return MI_RTJ_OK;
 }
 
@@ -563,12 +662,14 @@ int decode_one_launch(mi_rtj_ctx* c, const uint8_t* pkt, size_t len) {
   p->n_blocks = (uint64_t)f.nmb * 6;
   p->max_groups = (f.nmb + kMbPerGroup - 1) / kMbPerGroup;
   {
-    const int rc2 = plan_alloc_chunks(p);
-    if (rc2 != MI_RTJ_OK) return rc2;
     const char* mode = getenv("MI_RTJ_INDEX");
     p->serial_index = mode && strcmp(mode, "serial") == 0;
     const char* em = getenv("MI_RTJ_EMIT");
     p->emit_walk = em && strcmp(em, "walk") == 0;
+    const char* sp = getenv("MI_RTJ_SPEC");
+    p->spec_mode = sp ? atoi(sp) : -1;
+    const int rc2 = plan_alloc_chunks(p);
+    if (rc2 != MI_RTJ_OK) return rc2;
   }
   // pageable source: the runtime stages it; a private pinned staging copy measured no faster
   HIPCHK(c, hipMemcpyAsync(c->d_pkt, pkt, len, hipMemcpyHostToDevice, c->stream));

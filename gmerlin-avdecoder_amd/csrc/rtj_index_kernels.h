@@ -149,7 +149,8 @@ __global__ __launch_bounds__(kSumThreads, MIRTJ_SUM_WAVES) void k_index_summariz
                                                                   const uint8_t* __restrict__ stream,
                                                                   const QTab* __restrict__ lut,
                                                                   uint32_t* __restrict__ summary,
-                                                                  uint16_t* __restrict__ lentab) {
+                                                                  uint16_t* __restrict__ lentab,
+                                                                  const uint32_t* __restrict__ proven) {
   __shared__ __attribute__((aligned(16))) uint32_t s_b4[kStageN / 4];  // stream bytes
   __shared__ __attribute__((aligned(16))) uint16_t s_w[kStageN];       // inclusive weight sums mod 2^16
   __shared__ __attribute__((aligned(16))) uint8_t s_nl[kTabN];         // block length if luma ...
@@ -171,6 +172,7 @@ __global__ __launch_bounds__(kSumThreads, MIRTJ_SUM_WAVES) void k_index_summariz
   uint32_t* const s_res = (uint32_t*)(s_list + kEntries);  // (macroblocks << 16) | exit offset of each distinct target
 #endif
 
+  if (proven && proven[blockIdx.y]) return;  // the speculative index already holds this packet (rtj_spec_kernels.h)
   const FrameDev f = frames[blockIdx.y];
   const uint32_t c = blockIdx.x;
   if (c >= f.nchunks) return;
@@ -338,8 +340,10 @@ constexpr int kResTile = 24;
 __global__ __launch_bounds__(256) void k_index_resolve(const FrameDev* __restrict__ frames,
                                                         const uint32_t* __restrict__ summary,
                                                         uint32_t* __restrict__ chunk_pos,
-                                                        uint32_t* __restrict__ chunk_mb) {
+                                                        uint32_t* __restrict__ chunk_mb,
+                                                        const uint32_t* __restrict__ proven) {
   __shared__ uint32_t s_sum[kResTile * kEntries];
+  if (proven && proven[blockIdx.x]) return;
   __shared__ uint32_t s_state[2];
   const FrameDev f = frames[blockIdx.x];
   const int tid = threadIdx.x;
@@ -419,8 +423,10 @@ __global__ __launch_bounds__(kEmitThreads) void k_index_emit(const FrameDev* __r
                                                               const uint16_t* __restrict__ lentab,
                                                               const uint32_t* __restrict__ chunk_pos,
                                                               const uint32_t* __restrict__ chunk_mb,
-                                                              uint32_t* __restrict__ blkoff) {
-  __shared__ __attribute__((aligned(16))) uint16_t s_len[kTabN + 8];  // (luma | chroma << 8) per position
+                                                              uint32_t* __restrict__ blkoff,
+                                                              const uint32_t* __restrict__ proven) {
+  __shared__ __attribute__((aligned(16))) uint16_t s_len[kTabN + 8];
+  if (proven && proven[blockIdx.y]) return;  // (luma | chroma << 8) per position
   __shared__ uint16_t s_f[kChunk];   // macroblock length
   __shared__ uint16_t s_mb[kMaxMbPerChunk + 2];
   __shared__ uint32_t s_cnt[2];

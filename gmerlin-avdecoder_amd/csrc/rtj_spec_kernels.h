@@ -1,0 +1,271 @@
+// rtj_spec_kernels.h — the speculative block index (gfx950).
+//
+// The exact index (rtj_index_kernels.h) computes, for every 3584-byte chunk, where a macroblock walk
+// would leave the chunk from EVERY possible entry offset, because a chunk's true entry is only known
+// once all chunks before it are resolved.  On streams as encoders make them that generality is rarely
+// needed: a walk started at an arbitrary byte (as if a macroblock began there) falls into step with
+// the true block chain within a few hundred bytes — a block ends where its token slots are covered,
+// and the final zero run of a block covers them whatever the count was before — and, when luma and
+// chroma blocks carry different numbers of raw bytes, into step with the macroblock phase as well.
+//
+//   k_spec_walk    one LANE per chunk: starts kSpecLead bytes before its chunk, assuming a macroblock
+//                  starts there, and runs RTjpeg_s2b's length rule (lib/RTjpeg.c:157-186, 2704) as a
+//                  byte-serial state machine over lead + chunk + tail, recording every block start.
+//                  64 chunks advance in lockstep per wave: ~20 vector instructions per byte for 64
+//                  streams, against ~20 per BLOCK POSITION AND TYPE in k_index_summarize.
+//   k_spec_verify  per packet: the first (macro)block start a walker saw inside its chunk must be the
+//                  first one its predecessor saw past ITS chunk, and chunk 0 starts at byte 0.  By
+//                  induction every walker is then on the true chain from that point on, so the check
+//                  is exact, not a heuristic: it either proves the whole packet's index or rejects it.
+//                  Also counts blocks per chunk (prefix sums -> global block numbers).
+//   k_spec_expand  per chunk: recorded starts -> the block-offset index k_decode reads.
+//
+// Packets that fail the check (noisy content whose blocks end without a zero run, adversarial bytes,
+// packets that end early, more than kSpecCap blocks in a walker's span) keep ok == 0 and are indexed
+// by the exact kernels, which return at once for the others.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rtj_common.h"
+#include "rtj_decode_kernels.h"
+
+#ifndef MIRTJ_SPEC_CHUNK
+#define MIRTJ_SPEC_CHUNK 3584
+#endif
+#ifndef MIRTJ_SPEC_LEAD
+#define MIRTJ_SPEC_LEAD 512
+#endif
+
+namespace mirtj {
+
+constexpr int kSpecChunk = MIRTJ_SPEC_CHUNK;  // stream bytes a walker owns
+constexpr int kSpecLead = MIRTJ_SPEC_LEAD;   // bytes it parses before them, from an assumed macroblock start
+constexpr int kSpecTail = 512;    // and after them: the next macroblock start is within 6 * 64 bytes
+constexpr int kSpecSpan = kSpecLead + kSpecChunk + kSpecTail;
+constexpr int kSpecTile = 128;    // bytes per lane fetched at a time (one cache line)
+constexpr int kSpecCap = 1024;    // block starts a walker can record (16-bit, relative to its first byte)
+constexpr uint64_t kSpecMinWalkers = 8192;  // below this the exact kernels index a batch faster (host policy)
+constexpr int kSpecRingRow = 64 + 16;       // LDS bytes per lane of the record ring: 32 records + bank padding
+constexpr int kSpecRow = kSpecTile + 16;  // LDS bytes per lane: tile + the dword after it + bank padding
+static_assert(kSpecSpan % kSpecTile == 0 && kSpecSpan < 65536, "walker span: whole tiles, 16-bit positions");
+static_assert(kSpecTail >= 6 * 64 + 64, "a walker must reach the first macroblock start past its chunk");
+
+struct SpecChunkDev {
+  uint32_t frame;  // index into the plan's frames
+  uint32_t c;      // chunk number within the packet
+};
+struct SpecInfoDev {
+  uint32_t i0;       // index of the walker's first record that belongs to its chunk
+  uint32_t blkbase;  // number of blocks of the packet before it
+  uint32_t cnt;      // records of this chunk (for the last chunk: all that are left)
+};
+
+__global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ frames,
+                                                   const SpecChunkDev* __restrict__ chunks, uint32_t total,
+                                                   const uint8_t* __restrict__ stream,
+                                                   const QTab* __restrict__ lut, uint16_t* __restrict__ records,
+                                                   uint32_t* __restrict__ nrec) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_tile[64 * kSpecRow];
+  __shared__ __attribute__((aligned(16))) uint8_t s_ring[64 * kSpecRingRow];
+  const int lane = threadIdx.x;
+  const uint32_t g = blockIdx.x * 64u + (uint32_t)lane;
+  const bool act = g < total;
+  const SpecChunkDev sc = chunks[act ? g : total - 1u];  // idle lanes shadow the last chunk and store nothing
+  const FrameDev f = frames[sc.frame];
+  const int lb = lut[f.qidx].lb8 + 1, cb = lut[f.qidx].cb8 + 1;  // DC + raw bytes of a luma / chroma block
+  const uint32_t start = sc.c ? sc.c * (uint32_t)kSpecChunk - (uint32_t)kSpecLead : 0u;  // first byte parsed
+  const uint8_t* gp = stream + f.data_off + start;
+  const uint32_t sh = (uint32_t)((uintptr_t)gp & 3u);
+  const uint32_t* g4 = (const uint32_t*)(gp - sh);
+  // bytes of the packet from g4[0] on (start < data_len for every chunk but an empty packet's only one)
+  const int avail = (int)f.data_len - (int)start + (int)sh;
+  uint8_t* my = s_tile + lane * kSpecRow;
+
+  // ---- one tile = 32 dwords + the one after them (for the funnel shift), bytes past the packet read 0 ----
+  uint32_t buf[33];
+  auto request = [&](int t) {
+    const int d0 = t * (kSpecTile / 4);
+    if (__all(avail >= 4 * (d0 + 33))) {  // every lane's tile lies inside its packet
+#pragma unroll
+      for (int k = 0; k < 33; k++) buf[k] = g4[d0 + k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 33; k++) {
+        const int rem = avail - 4 * (d0 + k);
+        uint32_t v = 0;
+        if (rem > 0) {
+          v = g4[d0 + k];
+          if (rem < 4) v &= (1u << (8 * rem)) - 1u;
+        }
+        buf[k] = v;
+      }
+    }
+  };
+
+  // ---- the length rule as a branch-free state machine.  A block is complete after 64 units: DC and the
+  //      raw bytes count 1 each, a token its weight.  u = units of the current block so far, rb = its
+  //      1 + bt8 DC/raw bytes, ph = its number within the macroblock ----
+  int u = 0;
+  uint32_t ph = 0;
+  // record k = start of the walker's block k (phase k mod 6), 16-bit.  Records are staged in a 32-entry
+  // ring per lane in LDS and leave for HBM eight at a time (one 16-byte store): a 2-byte global store
+  // per block end was 40 % of the kernel.  Idle lanes of the last wave own the spare row after the last
+  // walker's.
+  const uint32_t row0 = 2u * (act ? g : total) * (uint32_t)kSpecCap;
+  uint8_t* const rec8 = (uint8_t*)records;
+  uint8_t* const ring = s_ring + lane * kSpecRingRow;
+  uint32_t cnt = 1, flushed = 0;
+  *(uint16_t*)ring = 0;
+  const int k63 = 63;
+  // pending = cnt - flushed as a signed number: the last, partial group leaves it negative
+  auto flush = [&](int least) {
+    while (__any((int)(cnt - flushed) >= least)) {
+      if ((int)(cnt - flushed) >= least) {
+        const uint4 v = *(const uint4*)(ring + ((flushed & 31u) << 1));  // flushed is a multiple of 8
+        if (flushed <= (uint32_t)kSpecCap - 8u) *(uint4*)(rec8 + row0 + 2u * flushed) = v;
+        flushed += 8u;
+      }
+    }
+  };
+
+  request(0);
+  for (int t = 0; t < kSpecSpan / kSpecTile; t++) {
+    {
+      uint4* row = (uint4*)my;
+#pragma unroll
+      for (int k = 0; k < 8; k++) row[k] = make_uint4(buf[4 * k], buf[4 * k + 1], buf[4 * k + 2], buf[4 * k + 3]);
+      *(uint32_t*)(my + kSpecTile) = buf[32];
+    }
+    if (t + 1 < kSpecSpan / kSpecTile) request(t + 1);  // in flight while this tile is parsed
+    for (int i = 0; i < kSpecTile / 16; i++) {
+      const uint4 q = *(const uint4*)(my + 16 * i);
+      const uint32_t q4 = *(const uint32_t*)(my + 16 * i + 16);
+      const uint32_t wd[4] = {__builtin_amdgcn_alignbyte(q.y, q.x, sh), __builtin_amdgcn_alignbyte(q.z, q.y, sh),
+                              __builtin_amdgcn_alignbyte(q.w, q.z, sh), __builtin_amdgcn_alignbyte(q4, q.w, sh)};
+      const uint32_t pos = (uint32_t)(t * kSpecTile + 16 * i);  // walker-relative position of wd's first byte
+#pragma unroll
+      for (int b = 0; b < 16; b++) {
+        const int t63 = sbyte_minus(wd[b >> 2], b & 3, k63);  // (int8)byte - 63; 0xFF -> -64
+        const int rb = ph < 4u ? lb : cb;
+        int wt = max(t63, 1);                                 // token weight (lib/RTjpeg.c:171-182)
+        if (u < rb) wt = (u == 0 && t63 == -64) ? 64 : 1;     // DC/raw byte; first byte 0xFF: one-byte block
+        u += wt;
+        // the next block would start at pos + b + 1: written to the ring's next slot every time, kept
+        // (the slot counter moves on) only when this byte ends its block
+        *(uint16_t*)(ring + ((cnt & 31u) << 1)) = (uint16_t)(pos + (uint32_t)b + 1u);
+        const bool end = u >= 64;
+        cnt += end ? 1u : 0u;
+        ph += end ? 1u : 0u;
+        ph = ph == 6u ? 0u : ph;
+        u = end ? 0 : u;
+      }
+      flush(8);  // at most 7 + 16 records are staged at this point
+    }
+  }
+  flush(1);  // the last, partial group (the slots past cnt are never read)
+  if (act) nrec[g] = cnt;  // > kSpecCap: the span held more blocks than a walker records
+}
+
+// first index in [0, n) whose record is >= v (records ascend), n if none
+__device__ __forceinline__ uint32_t spec_lower_bound(const uint16_t* __restrict__ r, uint32_t n, uint32_t v) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (r[mid] < v) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+// One workgroup per packet.
+__global__ __launch_bounds__(256) void k_spec_verify(const FrameDev* __restrict__ frames,
+                                                      const uint32_t* __restrict__ spec_base,
+                                                      const QTab* __restrict__ lut,
+                                                      const uint16_t* __restrict__ records,
+                                                      const uint32_t* __restrict__ nrec, SpecInfoDev* __restrict__ info,
+                                                      uint32_t* __restrict__ ok) {
+  __shared__ uint32_t s_e[256], s_wave[4], s_carry[3];  // carry: exit of the last chunk so far, blocks so far, bad
+  const FrameDev f = frames[blockIdx.x];
+  const uint32_t sc0 = spec_base[blockIdx.x], nsc = spec_base[blockIdx.x + 1] - sc0;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // lb8 == cb8: every block parses alike, walkers fall into step with the BLOCK chain but keep whatever
+  // macroblock phase they assumed; the unit of the chain check is then the block, and the phase follows
+  // from the global block number
+  const uint32_t unit = lut[f.qidx].lb8 == lut[f.qidx].cb8 ? 1u : 6u;
+  if (tid == 0) {
+    s_carry[0] = 0;  // chunk 0 must start at byte 0
+    s_carry[1] = 0;
+    s_carry[2] = 0;
+  }
+  __syncthreads();
+  for (uint32_t c0 = 0; c0 < nsc; c0 += 256) {
+    const uint32_t c = c0 + (uint32_t)tid;
+    uint32_t gpos = 0, epos = 0, cnt = 0, i0 = 0, bad = 0;
+    if (c < nsc) {
+      const uint32_t full = nrec[sc0 + c], n = min(full, (uint32_t)kSpecCap);
+      const uint16_t* R = records + (size_t)(sc0 + c) * kSpecCap;
+      const uint32_t start = c ? c * (uint32_t)kSpecChunk - (uint32_t)kSpecLead : 0u, loff = c ? (uint32_t)kSpecLead : 0u;
+      bad = full > (uint32_t)kSpecCap;  // the walker ran out of slots
+      i0 = (spec_lower_bound(R, n, loff) + unit - 1u) / unit * unit;
+      uint32_t i1 = n;  // the packet's last walker: everything it saw (bytes past the packet read as 0)
+      if (c + 1 < nsc) i1 = (spec_lower_bound(R, n, loff + (uint32_t)kSpecChunk) + unit - 1u) / unit * unit;
+      if (i0 >= n || (c + 1 < nsc && i1 >= n)) bad = 1;
+      else {
+        gpos = start + R[i0];
+        epos = c + 1 < nsc ? start + R[i1] : 0u;
+        cnt = i1 - i0;
+      }
+    }
+    // chain check against the predecessor's exit
+    s_e[tid] = epos;
+    __syncthreads();
+    if (c < nsc) {
+      const uint32_t prev = tid ? s_e[tid - 1] : s_carry[0];
+      if (gpos != prev) bad = 1;
+    }
+    // blocks before this chunk: scan over the tile + carry
+    const uint32_t incl = wave_incl_scan(cnt);
+    if (lane == 63) s_wave[wv] = incl;
+    const uint32_t anybad = __any(bad) ? 1u : 0u;
+    __syncthreads();
+    uint32_t before = s_carry[1] + incl - cnt;
+    for (int k = 0; k < wv; k++) before += s_wave[k];
+    if (c < nsc) {
+      SpecInfoDev o;
+      o.i0 = i0;
+      o.blkbase = before;
+      o.cnt = cnt;
+      info[sc0 + c] = o;
+    }
+    __syncthreads();
+    if (lane == 0 && anybad) atomicOr(&s_carry[2], 1u);
+    if (tid == 255) {
+      s_carry[0] = epos;
+      s_carry[1] = before + cnt;
+    }
+    __syncthreads();
+  }
+  // every block start and the end position must be there: indices 0 .. 6 * nmb
+  if (tid == 0) ok[blockIdx.x] = (!s_carry[2] && s_carry[1] >= 6u * f.nmb + 1u) ? 1u : 0u;
+}
+
+// One wave per chunk: the recorded starts of a proven packet become its block-offset index.
+__global__ __launch_bounds__(64) void k_spec_expand(const FrameDev* __restrict__ frames,
+                                                     const SpecChunkDev* __restrict__ chunks,
+                                                     const uint16_t* __restrict__ records,
+                                                     const SpecInfoDev* __restrict__ info,
+                                                     const uint32_t* __restrict__ ok, uint32_t* __restrict__ blkoff) {
+  const SpecChunkDev sc = chunks[blockIdx.x];
+  if (!ok[sc.frame]) return;
+  const FrameDev f = frames[sc.frame];
+  const SpecInfoDev in = info[blockIdx.x];
+  const uint32_t last = 6u * f.nmb;  // the index holds one entry past the last block: the end position
+  if (in.blkbase > last) return;
+  const uint32_t cnt = min(in.cnt, last + 1u - in.blkbase);
+  const uint32_t start = sc.c ? sc.c * (uint32_t)kSpecChunk - (uint32_t)kSpecLead : 0u;
+  const uint16_t* R = records + (size_t)blockIdx.x * kSpecCap + in.i0;
+  uint32_t* out = blkoff + f.blk_base + in.blkbase;
+  for (uint32_t k = threadIdx.x; k < cnt; k += 64) out[k] = start + R[k];
+}
+
+}  // namespace mirtj

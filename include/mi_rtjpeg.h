@@ -101,10 +101,17 @@ enum {
   MI_RTJ_K_RESOLVE = 1,   /* k_index_resolve: chain the summaries per packet */
   MI_RTJ_K_EMIT = 2,      /* k_index_emit (or k_index_walk with MI_RTJ_INDEX=serial): block offsets */
   MI_RTJ_K_DECODE = 3,    /* k_decode: dequant + IDCT + plane scatter */
-  MI_RTJ_NUM_KERNELS = 4
+  MI_RTJ_K_SPEC_WALK = 4,   /* k_spec_walk: speculative index, one lane per stream chunk */
+  MI_RTJ_K_SPEC_VERIFY = 5, /* k_spec_verify: proves or rejects it per packet */
+  MI_RTJ_K_SPEC_EXPAND = 6, /* k_spec_expand: proven block starts -> block offsets (kernels 0-2 then skip the packet) */
+  MI_RTJ_NUM_KERNELS = 7
 };
 void mi_rtj_plan_profile(mi_rtj_plan *plan, int enable);
 int mi_rtj_plan_times(mi_rtj_plan *plan, float ms[MI_RTJ_NUM_KERNELS], int *launches);
+/* After a decode: *walkers = stream chunks the speculative index covered (0: it was not used for this
+ * plan — small batch, MI_RTJ_SPEC=0, or an A/B index mode), *proven = packets whose index its proof step
+ * accepted; the others were indexed by the exact kernels.  Synchronises the instance's stream. */
+int mi_rtj_plan_spec_stats(mi_rtj_plan *plan, int *proven, long long *walkers);
 /* Test hook: copy the plan's block-start index (relative to each packet's first data byte,
  * nblocks+1 entries per frame, frames back to back) to the host after a decode. */
 int mi_rtj_plan_read_index(mi_rtj_plan *plan, uint32_t *dst, size_t max_entries);

@@ -1,0 +1,85 @@
+"""The speculative block index (csrc/rtj_spec_kernels.h) is switched on by batch size; MI_RTJ_SPEC=1
+forces it for every plan, also the one-packet path.  The parity tests are run again that way: streams
+an encoder made must come out of the speculative path (the exact kernels then skip the packet),
+adversarial ones must be rejected by its proof step and indexed by the exact kernels — either way the
+block index and the planes equal the oracle's."""
+import numpy as np
+import pytest
+
+import rtjlib as R
+import test_gpu_parity as T
+from pkg import P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def dev(monkeypatch):
+    monkeypatch.setenv("MI_RTJ_SPEC", "1")
+    d = P.MiRtj()
+    yield d
+    d.close()
+
+
+@pytest.fixture(scope="module")
+def G():
+    return np.load(R.GOLDEN + "/rtjpeg_golden.npz")
+
+
+def test_golden_vectors(dev, G):
+    T.test_golden_intra_streams_batch(dev, G)
+    T.test_golden_adversarial_known_answers(dev, G)
+
+
+@pytest.mark.parametrize("w,h,Q,amp,n", [(320, 240, 255, 8, 6), (320, 240, 128, 64, 3), (336, 256, 1, 64, 2),
+                                          (1920, 1088, 255, 8, 2), (1920, 1088, 64, 64, 1), (4096, 16, 90, 20, 2)])
+def test_decode_matches_oracle(dev, w, h, Q, amp, n):
+    T.test_decode_matches_oracle(dev, w, h, Q, amp, n)
+
+
+def test_mixed_batches_skip_blocks_truncation_and_fuzz(dev):
+    T.test_mixed_batch_sizes_and_qualities(dev)
+    T.test_skip_blocks_leave_destination_untouched_in_batches(dev)
+    T.test_truncated_and_empty_packets(dev)
+    T.test_chunk_boundaries_and_long_blocks(dev)
+    T.test_fuzz_arbitrary_bytes(dev)
+    T.test_low_4x4_transform_path_and_its_boundary(dev)
+
+
+def test_one_packet_path_and_inter_stream(dev, G, monkeypatch):
+    monkeypatch.setenv("MI_RTJ_SPEC", "1")
+    T.test_golden_inter_sequence_single_stream(dev, G)
+    T.test_random_token_streams(dev)
+    T.test_quality_zero_state_machine(dev)
+
+
+def test_speculation_is_taken_or_refused_as_expected(dev):
+    """Encoder-made 1080p packets are proven; a packet of random bytes is refused."""
+    w, h = 1920, 1088
+    good = [R.OracleEncoder(w, h, 255).encode(R.synth_frame(w, h, i, amp=8)) for i in range(2)]
+    rng = np.random.default_rng(1)
+    n = 600000
+    total = 12 + n
+    hdr = np.array([total & 255, (total >> 8) & 255, (total >> 16) & 255, 0, 12, 0, w & 255, w >> 8, h & 255, h >> 8, 200, 0], np.uint8)
+    bad = [np.concatenate([hdr, rng.integers(0, 256, n, dtype=np.uint8)])]
+    for pkts, want_fallback in ((good, False), (bad, True)):
+        d_stream, po, pl, hdrs = dev.upload_packets(pkts, align=1)
+        fsz = T.frame_bytes(w, h)
+        d_out = dev.alloc(fsz * len(pkts))
+        plan = dev.plan(hdrs, po, pl, np.arange(len(pkts), dtype=np.uint64) * np.uint64(fsz))
+        plan.decode(d_stream, d_out)
+        dev.sync()
+        plan.profile(True)
+        plan.decode(d_stream, d_out)
+        ms, _ = plan.times()
+        dec = R.OracleDecoder()
+        for i, p in enumerate(pkts):
+            wantp = np.zeros(fsz, np.uint8)
+            dec.decode(p, wantp)
+            assert np.array_equal(dev.d2h(d_out, fsz, offset=i * fsz), wantp)
+        assert ms["k_spec_walk"] > 0
+        proven, walkers = plan.spec_stats()
+        assert walkers > 0 and proven == (0 if want_fallback else len(pkts)), (proven, walkers)
+        plan.close()
+        dev.free(d_stream)
+        dev.free(d_out)
