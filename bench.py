@@ -182,7 +182,7 @@ def main():
         # per-launch figures of every kernel of the path (this rank), from HIP events on the launch stream
         alg_bytes = info["bytes_in"] + info["bytes_out"]  # packet read once + planes written once
         alg = {"k_index_summarize": info["bytes_in"], "k_index_resolve": 0, "k_index_emit": info["bytes_in"],
-               "k_decode": alg_bytes, "k_spec_walk": info["bytes_in"], "k_spec_verify": 0, "k_spec_expand": 0}
+               "k_decode": alg_bytes, "k_spec_walk": info["bytes_in"], "k_spec_verify": 0}
         kernels = {}
         for name, ms in ktimes.items():
             per = ms / max(launches, 1)

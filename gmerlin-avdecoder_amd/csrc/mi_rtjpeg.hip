@@ -80,8 +80,8 @@ struct mi_rtj_plan {
   uint32_t* d_spec_base = nullptr;
   uint16_t* d_spec_rec = nullptr;          // [walkers][kSpecCap]
   uint32_t* d_spec_nrec = nullptr;
-  SpecInfoDev* d_spec_info = nullptr;
-  uint32_t* d_spec_ok = nullptr;           // [n]: 1 = the packet's index is proven, the exact kernels skip it
+  uint32_t* d_spec_ok = nullptr;           // [n]: 1 = the packet's index is proven
+  uint32_t* d_spec_todo = nullptr;         // [n + 1]: count, then the packets left to the exact kernels
   int cap_spec_frames = 0;
   std::vector<Timed> ev[MI_RTJ_NUM_KERNELS];  // one pair per launch while profiling
   int launches = 0;
@@ -214,13 +214,11 @@ int plan_alloc_chunks(mi_rtj_plan* p) {
         (void)hipFree(p->d_spec_chunks);
         (void)hipFree(p->d_spec_rec);
         (void)hipFree(p->d_spec_nrec);
-        (void)hipFree(p->d_spec_info);
         p->d_spec_chunks = nullptr;
       }
       HIPCHK(c, hipMalloc((void**)&p->d_spec_chunks, sizeof(SpecChunkDev) * p->n_spec));
       HIPCHK(c, hipMalloc((void**)&p->d_spec_rec, sizeof(uint16_t) * kSpecCap * (p->n_spec + 1)));  // + a spare row for idle lanes
       HIPCHK(c, hipMalloc((void**)&p->d_spec_nrec, sizeof(uint32_t) * p->n_spec));
-      HIPCHK(c, hipMalloc((void**)&p->d_spec_info, sizeof(SpecInfoDev) * p->n_spec));
       p->cap_spec = p->n_spec;
     }
     if ((int)p->h_frames.size() > p->cap_spec_frames) {
@@ -228,9 +226,11 @@ int plan_alloc_chunks(mi_rtj_plan* p) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         (void)hipFree(p->d_spec_base);
         (void)hipFree(p->d_spec_ok);
+        (void)hipFree(p->d_spec_todo);
       }
       HIPCHK(c, hipMalloc((void**)&p->d_spec_base, sizeof(uint32_t) * (p->h_frames.size() + 1)));
       HIPCHK(c, hipMalloc((void**)&p->d_spec_ok, sizeof(uint32_t) * p->h_frames.size()));
+      HIPCHK(c, hipMalloc((void**)&p->d_spec_todo, sizeof(uint32_t) * (p->h_frames.size() + 1)));
       p->cap_spec_frames = (int)p->h_frames.size();
     }
     HIPCHK(c, hipMemcpyAsync(p->d_spec_chunks, p->h_spec_chunks.data(), sizeof(SpecChunkDev) * p->n_spec, hipMemcpyHostToDevice, c->stream));
@@ -271,41 +271,41 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
     hipLaunchKernelGGL(k_index_walk, dim3(p->n), dim3(64), 0, c->stream, p->d_frames, st, c->d_lut, p->d_blkoff);
     if ((rc = end(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
   } else {
-    const uint32_t* ok = nullptr;
+    const uint32_t *todo = nullptr, *ntodo = nullptr;
+    unsigned rows = (unsigned)p->n;  // grid rows of the exact kernels: one per packet, or a few that loop over the to-do list
     if (p->spec) {
-      ok = p->d_spec_ok;
+      ntodo = p->d_spec_todo;
+      todo = p->d_spec_todo + 1;
+      rows = std::min<unsigned>(rows, kSpecFallbackRows);
+      HIPCHK(c, hipMemsetAsync(p->d_spec_todo, 0, sizeof(uint32_t), c->stream));
       if ((rc = begin(MI_RTJ_K_SPEC_WALK)) != MI_RTJ_OK) return rc;
       hipLaunchKernelGGL(k_spec_walk, dim3((unsigned)((p->n_spec + 63) / 64)), dim3(64), 0, c->stream, p->d_frames,
                          p->d_spec_chunks, (uint32_t)p->n_spec, st, c->d_lut, p->d_spec_rec, p->d_spec_nrec);
       if ((rc = end(MI_RTJ_K_SPEC_WALK)) != MI_RTJ_OK) return rc;
       if ((rc = begin(MI_RTJ_K_SPEC_VERIFY)) != MI_RTJ_OK) return rc;
-      hipLaunchKernelGGL(k_spec_verify, dim3(p->n), dim3(256), 0, c->stream, p->d_frames, p->d_spec_base, c->d_lut,
-                         p->d_spec_rec, p->d_spec_nrec, p->d_spec_info, p->d_spec_ok);
+      hipLaunchKernelGGL(k_spec_verify, dim3(p->n), dim3(kSpecVerThreads), 0, c->stream, p->d_frames, p->d_spec_base, c->d_lut,
+                         p->d_spec_rec, p->d_spec_nrec, p->d_blkoff, p->d_spec_ok, p->d_spec_todo + 1, p->d_spec_todo);
       if ((rc = end(MI_RTJ_K_SPEC_VERIFY)) != MI_RTJ_OK) return rc;
-      if ((rc = begin(MI_RTJ_K_SPEC_EXPAND)) != MI_RTJ_OK) return rc;
-      hipLaunchKernelGGL(k_spec_expand, dim3((unsigned)p->n_spec), dim3(64), 0, c->stream, p->d_frames,
-                         p->d_spec_chunks, p->d_spec_rec, p->d_spec_info, p->d_spec_ok, p->d_blkoff);
-      if ((rc = end(MI_RTJ_K_SPEC_EXPAND)) != MI_RTJ_OK) return rc;
     }
     if ((rc = begin(MI_RTJ_K_SUMMARIZE)) != MI_RTJ_OK) return rc;
     if (p->one_block_type)
-      hipLaunchKernelGGL(k_index_summarize<1>, dim3(p->max_chunks, p->n), dim3(kSumThreads), 0, c->stream, p->d_frames,
-                         st, c->d_lut, p->d_summary, p->d_lentab, ok);
+      hipLaunchKernelGGL(k_index_summarize<1>, dim3(p->max_chunks, rows), dim3(kSumThreads), 0, c->stream, p->d_frames,
+                         st, c->d_lut, p->d_summary, p->d_lentab, todo, ntodo);
     else
-      hipLaunchKernelGGL(k_index_summarize<2>, dim3(p->max_chunks, p->n), dim3(kSumThreads), 0, c->stream, p->d_frames,
-                         st, c->d_lut, p->d_summary, p->d_lentab, ok);
+      hipLaunchKernelGGL(k_index_summarize<2>, dim3(p->max_chunks, rows), dim3(kSumThreads), 0, c->stream, p->d_frames,
+                         st, c->d_lut, p->d_summary, p->d_lentab, todo, ntodo);
     if ((rc = end(MI_RTJ_K_SUMMARIZE)) != MI_RTJ_OK) return rc;
     if ((rc = begin(MI_RTJ_K_RESOLVE)) != MI_RTJ_OK) return rc;
-    hipLaunchKernelGGL(k_index_resolve, dim3(p->n), dim3(256), 0, c->stream, p->d_frames, p->d_summary,
-                       p->d_chunk_pos, p->d_chunk_mb, ok);
+    hipLaunchKernelGGL(k_index_resolve, dim3(todo ? std::min<unsigned>((unsigned)p->n, 1024u) : rows), dim3(256), 0, c->stream, p->d_frames, p->d_summary,
+                       p->d_chunk_pos, p->d_chunk_mb, todo, ntodo);
     if ((rc = end(MI_RTJ_K_RESOLVE)) != MI_RTJ_OK) return rc;
     if ((rc = begin(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
     if (p->emit_walk)
       hipLaunchKernelGGL(k_index_emit_walk, dim3(p->max_chunks, p->n), dim3(64), 0, c->stream, p->d_frames, st,
                          c->d_lut, p->d_chunk_pos, p->d_chunk_mb, p->d_blkoff);
     else
-      hipLaunchKernelGGL(k_index_emit, dim3(p->max_chunks, p->n), dim3(kEmitThreads), 0, c->stream, p->d_frames,
-                         p->d_lentab, p->d_chunk_pos, p->d_chunk_mb, p->d_blkoff, ok);
+      hipLaunchKernelGGL(k_index_emit, dim3(p->max_chunks, rows), dim3(kEmitThreads), 0, c->stream, p->d_frames,
+                         p->d_lentab, p->d_chunk_pos, p->d_chunk_mb, p->d_blkoff, todo, ntodo);
     if ((rc = end(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
   }
   if ((rc = begin(MI_RTJ_K_DECODE)) != MI_RTJ_OK) return rc;
@@ -535,7 +535,7 @@ void mi_rtj_plan_destroy(mi_rtj_plan* p) {
   if (p->d_spec_base) (void)hipFree(p->d_spec_base);
   if (p->d_spec_rec) (void)hipFree(p->d_spec_rec);
   if (p->d_spec_nrec) (void)hipFree(p->d_spec_nrec);
-  if (p->d_spec_info) (void)hipFree(p->d_spec_info);
+  if (p->d_spec_todo) (void)hipFree(p->d_spec_todo);
   if (p->d_spec_ok) (void)hipFree(p->d_spec_ok);
   delete p;
 }

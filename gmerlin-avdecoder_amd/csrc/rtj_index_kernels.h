@@ -145,12 +145,9 @@ __device__ __forceinline__ void patch_unchanged_blocks(const uint32_t* s_b4, uin
 }
 
 template <int NT>
-__global__ __launch_bounds__(kSumThreads, MIRTJ_SUM_WAVES) void k_index_summarize(const FrameDev* __restrict__ frames,
-                                                                  const uint8_t* __restrict__ stream,
-                                                                  const QTab* __restrict__ lut,
-                                                                  uint32_t* __restrict__ summary,
-                                                                  uint16_t* __restrict__ lentab,
-                                                                  const uint32_t* __restrict__ proven) {
+__device__ __forceinline__ void summarize_chunk(const FrameDev* __restrict__ frames, const uint8_t* __restrict__ stream,
+                                                const QTab* __restrict__ lut, uint32_t* __restrict__ summary,
+                                                uint16_t* __restrict__ lentab, uint32_t frame_index) {
   __shared__ __attribute__((aligned(16))) uint32_t s_b4[kStageN / 4];  // stream bytes
   __shared__ __attribute__((aligned(16))) uint16_t s_w[kStageN];       // inclusive weight sums mod 2^16
   __shared__ __attribute__((aligned(16))) uint8_t s_nl[kTabN];         // block length if luma ...
@@ -172,8 +169,7 @@ __global__ __launch_bounds__(kSumThreads, MIRTJ_SUM_WAVES) void k_index_summariz
   uint32_t* const s_res = (uint32_t*)(s_list + kEntries);  // (macroblocks << 16) | exit offset of each distinct target
 #endif
 
-  if (proven && proven[blockIdx.y]) return;  // the speculative index already holds this packet (rtj_spec_kernels.h)
-  const FrameDev f = frames[blockIdx.y];
+  const FrameDev f = frames[frame_index];
   const uint32_t c = blockIdx.x;
   if (c >= f.nchunks) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -335,17 +331,35 @@ __global__ __launch_bounds__(kSumThreads, MIRTJ_SUM_WAVES) void k_index_summariz
   if (two) out[tid + kSumThreads] = s_res[s_slot[h1]];
 }
 
+// grid (chunks, frames).  With a to-do list (the packets the speculative index refused, rtj_spec_kernels.h)
+// the rows of the grid loop over that list instead.
+template <int NT>
+__global__ __launch_bounds__(kSumThreads, MIRTJ_SUM_WAVES) void k_index_summarize(const FrameDev* __restrict__ frames,
+                                                                  const uint8_t* __restrict__ stream,
+                                                                  const QTab* __restrict__ lut,
+                                                                  uint32_t* __restrict__ summary,
+                                                                  uint16_t* __restrict__ lentab,
+                                                                  const uint32_t* __restrict__ todo,
+                                                                  const uint32_t* __restrict__ ntodo) {
+  if (!todo) {
+    summarize_chunk<NT>(frames, stream, lut, summary, lentab, blockIdx.y);
+    return;
+  }
+  const uint32_t n = *ntodo;
+  for (uint32_t i = blockIdx.y; i < n; i += gridDim.y) {
+    summarize_chunk<NT>(frames, stream, lut, summary, lentab, todo[i]);
+    __syncthreads();  // the next packet's chunk reuses the LDS
+  }
+}
+
 // One workgroup per packet.  Summaries are pulled through LDS a tile at a time; lane 0 chains them.
 constexpr int kResTile = 24;
-__global__ __launch_bounds__(256) void k_index_resolve(const FrameDev* __restrict__ frames,
-                                                        const uint32_t* __restrict__ summary,
-                                                        uint32_t* __restrict__ chunk_pos,
-                                                        uint32_t* __restrict__ chunk_mb,
-                                                        const uint32_t* __restrict__ proven) {
+__device__ __forceinline__ void resolve_packet(const FrameDev* __restrict__ frames, const uint32_t* __restrict__ summary,
+                                               uint32_t* __restrict__ chunk_pos, uint32_t* __restrict__ chunk_mb,
+                                               uint32_t frame_index) {
   __shared__ uint32_t s_sum[kResTile * kEntries];
-  if (proven && proven[blockIdx.x]) return;
   __shared__ uint32_t s_state[2];
-  const FrameDev f = frames[blockIdx.x];
+  const FrameDev f = frames[frame_index];
   const int tid = threadIdx.x;
   if (tid == 0) {
     s_state[0] = 0;  // entry offset into the current chunk
@@ -394,6 +408,23 @@ __global__ __launch_bounds__(256) void k_index_resolve(const FrameDev* __restric
   }
 }
 
+__global__ __launch_bounds__(256) void k_index_resolve(const FrameDev* __restrict__ frames,
+                                                        const uint32_t* __restrict__ summary,
+                                                        uint32_t* __restrict__ chunk_pos,
+                                                        uint32_t* __restrict__ chunk_mb,
+                                                        const uint32_t* __restrict__ todo,
+                                                        const uint32_t* __restrict__ ntodo) {
+  if (!todo) {
+    resolve_packet(frames, summary, chunk_pos, chunk_mb, blockIdx.x);
+    return;
+  }
+  const uint32_t n = *ntodo;
+  for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+    resolve_packet(frames, summary, chunk_pos, chunk_mb, todo[i]);
+    __syncthreads();
+  }
+}
+
 // A/B baseline of k_index_emit (MI_RTJ_EMIT=walk): one wave per chunk re-walks the chunk's own
 // blocks from the stream bytes.
 __global__ __launch_bounds__(64) void k_index_emit_walk(const FrameDev* __restrict__ frames,
@@ -419,19 +450,15 @@ __global__ __launch_bounds__(64) void k_index_emit_walk(const FrameDev* __restri
 #endif
 constexpr int kEmitThreads = MIRTJ_EMIT_THREADS;
 constexpr int kMaxMbPerChunk = kChunk / 6 + 2;  // a macroblock is at least six 1-byte blocks
-__global__ __launch_bounds__(kEmitThreads) void k_index_emit(const FrameDev* __restrict__ frames,
-                                                              const uint16_t* __restrict__ lentab,
-                                                              const uint32_t* __restrict__ chunk_pos,
-                                                              const uint32_t* __restrict__ chunk_mb,
-                                                              uint32_t* __restrict__ blkoff,
-                                                              const uint32_t* __restrict__ proven) {
-  __shared__ __attribute__((aligned(16))) uint16_t s_len[kTabN + 8];
-  if (proven && proven[blockIdx.y]) return;  // (luma | chroma << 8) per position
+__device__ __forceinline__ void emit_chunk(const FrameDev* __restrict__ frames, const uint16_t* __restrict__ lentab,
+                                           const uint32_t* __restrict__ chunk_pos, const uint32_t* __restrict__ chunk_mb,
+                                           uint32_t* __restrict__ blkoff, uint32_t frame_index) {
+  __shared__ __attribute__((aligned(16))) uint16_t s_len[kTabN + 8];  // (luma | chroma << 8) per position
   __shared__ uint16_t s_f[kChunk];   // macroblock length
   __shared__ uint16_t s_mb[kMaxMbPerChunk + 2];
   __shared__ uint32_t s_cnt[2];
 
-  const FrameDev f = frames[blockIdx.y];
+  const FrameDev f = frames[frame_index];
   const uint32_t c = blockIdx.x;
   if (c >= f.nchunks) return;
   const int tid = threadIdx.x;
@@ -523,6 +550,24 @@ __global__ __launch_bounds__(kEmitThreads) void k_index_emit(const FrameDev* __r
   const uint32_t n_tail = (m1 - m0) - n_in;
   for (uint32_t i = tid; i < n_tail * 6u; i += kEmitThreads) out[6u * (m0 + n_in) + i] = cbase + q_end + 64u * i;
   if (tid == 0 && m1 == f.nmb) out[6u * f.nmb] = cbase + q_end + 384u * n_tail;
+}
+
+__global__ __launch_bounds__(kEmitThreads) void k_index_emit(const FrameDev* __restrict__ frames,
+                                                              const uint16_t* __restrict__ lentab,
+                                                              const uint32_t* __restrict__ chunk_pos,
+                                                              const uint32_t* __restrict__ chunk_mb,
+                                                              uint32_t* __restrict__ blkoff,
+                                                              const uint32_t* __restrict__ todo,
+                                                              const uint32_t* __restrict__ ntodo) {
+  if (!todo) {
+    emit_chunk(frames, lentab, chunk_pos, chunk_mb, blkoff, blockIdx.y);
+    return;
+  }
+  const uint32_t n = *ntodo;
+  for (uint32_t i = blockIdx.y; i < n; i += gridDim.y) {
+    emit_chunk(frames, lentab, chunk_pos, chunk_mb, blkoff, todo[i]);
+    __syncthreads();
+  }
 }
 
 }  // namespace mirtj

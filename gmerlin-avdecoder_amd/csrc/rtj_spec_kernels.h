@@ -17,12 +17,12 @@
 //                  first one its predecessor saw past ITS chunk, and chunk 0 starts at byte 0.  By
 //                  induction every walker is then on the true chain from that point on, so the check
 //                  is exact, not a heuristic: it either proves the whole packet's index or rejects it.
-//                  Also counts blocks per chunk (prefix sums -> global block numbers).
-//   k_spec_expand  per chunk: recorded starts -> the block-offset index k_decode reads.
+//                  Also counts blocks per chunk (prefix sums -> global block numbers) and turns the
+//                  recorded starts into the block-offset index k_decode reads.
 //
 // Packets that fail the check (noisy content whose blocks end without a zero run, adversarial bytes,
-// packets that end early, more than kSpecCap blocks in a walker's span) keep ok == 0 and are indexed
-// by the exact kernels, which return at once for the others.
+// packets that end early, more than kSpecCap blocks in a walker's span) are put on a to-do list; the
+// exact kernels run over that list only (a grid of kSpecFallbackRows rows that loops).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -54,11 +54,11 @@ struct SpecChunkDev {
   uint32_t frame;  // index into the plan's frames
   uint32_t c;      // chunk number within the packet
 };
-struct SpecInfoDev {
-  uint32_t i0;       // index of the walker's first record that belongs to its chunk
-  uint32_t blkbase;  // number of blocks of the packet before it
-  uint32_t cnt;      // records of this chunk (for the last chunk: all that are left)
-};
+constexpr int kSpecFallbackRows = 64;
+#ifndef MIRTJ_SPEC_VER_THREADS
+#define MIRTJ_SPEC_VER_THREADS 1024
+#endif
+constexpr int kSpecVerThreads = MIRTJ_SPEC_VER_THREADS;  // k_spec_verify: chunks of a packet handled side by side  // grid rows of the exact kernels when they only serve refused packets
 
 __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ frames,
                                                    const SpecChunkDev* __restrict__ chunks, uint32_t total,
@@ -177,14 +177,18 @@ __device__ __forceinline__ uint32_t spec_lower_bound(const uint16_t* __restrict_
   return lo;
 }
 
-// One workgroup per packet.
-__global__ __launch_bounds__(256) void k_spec_verify(const FrameDev* __restrict__ frames,
+// One workgroup per packet: the chain check, the block numbering, and — the numbering is all it needs —
+// the block-offset index itself.  A packet that fails goes on the exact kernels' to-do list (they then
+// rewrite its index).
+__global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev* __restrict__ frames,
                                                       const uint32_t* __restrict__ spec_base,
                                                       const QTab* __restrict__ lut,
                                                       const uint16_t* __restrict__ records,
-                                                      const uint32_t* __restrict__ nrec, SpecInfoDev* __restrict__ info,
-                                                      uint32_t* __restrict__ ok) {
-  __shared__ uint32_t s_e[256], s_wave[4], s_carry[3];  // carry: exit of the last chunk so far, blocks so far, bad
+                                                      const uint32_t* __restrict__ nrec, uint32_t* __restrict__ blkoff,
+                                                      uint32_t* __restrict__ ok, uint32_t* __restrict__ todo,
+                                                      uint32_t* __restrict__ ntodo) {
+  __shared__ uint32_t s_e[kSpecVerThreads], s_wave[kSpecVerThreads / 64], s_carry[3];  // carry: exit of the last chunk so far, blocks so far, bad
+  __shared__ uint32_t s_i0[kSpecVerThreads], s_base[kSpecVerThreads], s_cnt[kSpecVerThreads];
   const FrameDev f = frames[blockIdx.x];
   const uint32_t sc0 = spec_base[blockIdx.x], nsc = spec_base[blockIdx.x + 1] - sc0;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -192,13 +196,15 @@ __global__ __launch_bounds__(256) void k_spec_verify(const FrameDev* __restrict_
   // macroblock phase they assumed; the unit of the chain check is then the block, and the phase follows
   // from the global block number
   const uint32_t unit = lut[f.qidx].lb8 == lut[f.qidx].cb8 ? 1u : 6u;
+  const uint32_t last = 6u * f.nmb;  // the index holds one entry past the last block: the end position
+  uint32_t* const out = blkoff + f.blk_base;
   if (tid == 0) {
     s_carry[0] = 0;  // chunk 0 must start at byte 0
     s_carry[1] = 0;
     s_carry[2] = 0;
   }
   __syncthreads();
-  for (uint32_t c0 = 0; c0 < nsc; c0 += 256) {
+  for (uint32_t c0 = 0; c0 < nsc; c0 += kSpecVerThreads) {
     const uint32_t c = c0 + (uint32_t)tid;
     uint32_t gpos = 0, epos = 0, cnt = 0, i0 = 0, bad = 0;
     if (c < nsc) {
@@ -230,42 +236,48 @@ __global__ __launch_bounds__(256) void k_spec_verify(const FrameDev* __restrict_
     __syncthreads();
     uint32_t before = s_carry[1] + incl - cnt;
     for (int k = 0; k < wv; k++) before += s_wave[k];
-    if (c < nsc) {
-      SpecInfoDev o;
-      o.i0 = i0;
-      o.blkbase = before;
-      o.cnt = cnt;
-      info[sc0 + c] = o;
-    }
+    s_i0[tid] = i0;
+    s_base[tid] = before;
+    s_cnt[tid] = cnt;
     __syncthreads();
     if (lane == 0 && anybad) atomicOr(&s_carry[2], 1u);
-    if (tid == 255) {
+    if (tid == kSpecVerThreads - 1) {
       s_carry[0] = epos;
       s_carry[1] = before + cnt;
+    }
+    // recorded starts -> block offsets, one wave per chunk of the tile (harmless if the packet fails later:
+    // counts of refused chunks are 0, everything is clipped to the packet's own index, and the exact
+    // kernels rewrite it)
+    const uint32_t tile_n = min((uint32_t)kSpecVerThreads, nsc - c0);
+    for (uint32_t j = (uint32_t)wv; j < tile_n; j += kSpecVerThreads / 64) {
+      const uint32_t cj = c0 + j, base = s_base[j];
+      if (base > last) break;  // bases ascend
+      const uint32_t m = min(s_cnt[j], last + 1u - base);
+      const uint32_t start = cj ? cj * (uint32_t)kSpecChunk - (uint32_t)kSpecLead : 0u;
+      const uint16_t* R = records + (size_t)(sc0 + cj) * kSpecCap + s_i0[j];
+      // a chunk holds ~200 blocks: four loads in flight per lane, so that a chunk costs one round trip
+      for (uint32_t k0 = 0; k0 < m; k0 += 256) {
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const uint32_t k = k0 + 64u * (uint32_t)u + (uint32_t)lane;
+          v[u] = k < m ? R[k] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const uint32_t k = k0 + 64u * (uint32_t)u + (uint32_t)lane;
+          if (k < m) out[base + k] = start + v[u];
+        }
+      }
     }
     __syncthreads();
   }
   // every block start and the end position must be there: indices 0 .. 6 * nmb
-  if (tid == 0) ok[blockIdx.x] = (!s_carry[2] && s_carry[1] >= 6u * f.nmb + 1u) ? 1u : 0u;
-}
-
-// One wave per chunk: the recorded starts of a proven packet become its block-offset index.
-__global__ __launch_bounds__(64) void k_spec_expand(const FrameDev* __restrict__ frames,
-                                                     const SpecChunkDev* __restrict__ chunks,
-                                                     const uint16_t* __restrict__ records,
-                                                     const SpecInfoDev* __restrict__ info,
-                                                     const uint32_t* __restrict__ ok, uint32_t* __restrict__ blkoff) {
-  const SpecChunkDev sc = chunks[blockIdx.x];
-  if (!ok[sc.frame]) return;
-  const FrameDev f = frames[sc.frame];
-  const SpecInfoDev in = info[blockIdx.x];
-  const uint32_t last = 6u * f.nmb;  // the index holds one entry past the last block: the end position
-  if (in.blkbase > last) return;
-  const uint32_t cnt = min(in.cnt, last + 1u - in.blkbase);
-  const uint32_t start = sc.c ? sc.c * (uint32_t)kSpecChunk - (uint32_t)kSpecLead : 0u;
-  const uint16_t* R = records + (size_t)blockIdx.x * kSpecCap + in.i0;
-  uint32_t* out = blkoff + f.blk_base + in.blkbase;
-  for (uint32_t k = threadIdx.x; k < cnt; k += 64) out[k] = start + R[k];
+  if (tid == 0) {
+    const uint32_t good = (!s_carry[2] && s_carry[1] >= last + 1u) ? 1u : 0u;
+    ok[blockIdx.x] = good;
+    if (!good) todo[atomicAdd(ntodo, 1u)] = blockIdx.x;
+  }
 }
 
 }  // namespace mirtj

@@ -102,9 +102,9 @@ enum {
   MI_RTJ_K_EMIT = 2,      /* k_index_emit (or k_index_walk with MI_RTJ_INDEX=serial): block offsets */
   MI_RTJ_K_DECODE = 3,    /* k_decode: dequant + IDCT + plane scatter */
   MI_RTJ_K_SPEC_WALK = 4,   /* k_spec_walk: speculative index, one lane per stream chunk */
-  MI_RTJ_K_SPEC_VERIFY = 5, /* k_spec_verify: proves or rejects it per packet */
-  MI_RTJ_K_SPEC_EXPAND = 6, /* k_spec_expand: proven block starts -> block offsets (kernels 0-2 then skip the packet) */
-  MI_RTJ_NUM_KERNELS = 7
+  MI_RTJ_K_SPEC_VERIFY = 5, /* k_spec_verify: proves or rejects it per packet, writes the proven block offsets
+                             * (kernels 0-2 then only serve the rejected packets) */
+  MI_RTJ_NUM_KERNELS = 6
 };
 void mi_rtj_plan_profile(mi_rtj_plan *plan, int enable);
 int mi_rtj_plan_times(mi_rtj_plan *plan, float ms[MI_RTJ_NUM_KERNELS], int *launches);
