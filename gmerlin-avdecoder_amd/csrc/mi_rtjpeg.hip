@@ -71,7 +71,7 @@ struct mi_rtj_plan {
   bool emit_walk = false;           // MI_RTJ_EMIT=walk: per-chunk re-walk instead of the length tables
   bool one_block_type = false;      // every frame's tables have lb8 == cb8: single-search summarize
   // speculative index (rtj_spec_kernels.h): one walker per kSpecChunk bytes, proven per packet afterwards
-  int spec_mode = -1;               // MI_RTJ_SPEC: 0 never, 1 always, otherwise by batch size
+  int spec_mode = -1;               // MI_RTJ_SPEC: 0 never, 1 always (no pausing), 2 whatever the batch size, otherwise by batch size
   bool spec = false;
   uint64_t n_spec = 0, cap_spec = 0;       // walkers of this plan / allocated
   std::vector<SpecChunkDev> h_spec_chunks;
@@ -83,6 +83,7 @@ struct mi_rtj_plan {
   uint32_t* d_spec_ok = nullptr;           // [n]: 1 = the packet's index is proven
   uint32_t* d_spec_todo = nullptr;         // [n + 1]: count, then the packets left to the exact kernels
   int cap_spec_frames = 0;
+  uint32_t* d_spec_state = nullptr;        // [2]: launches in a row that refused every packet, launches left paused
   std::vector<Timed> ev[MI_RTJ_NUM_KERNELS];  // one pair per launch while profiling
   int launches = 0;
 };
@@ -194,7 +195,7 @@ int plan_alloc_chunks(mi_rtj_plan* p) {
   //      for ~0.25 ms whatever the batch; a single packet is indexed faster by the exact kernels) ----
   uint64_t walkers = 0;
   for (auto& f : p->h_frames) walkers += f.data_len ? (f.data_len + kSpecChunk - 1) / kSpecChunk : 1;
-  p->spec = !p->serial_index && !p->emit_walk && (p->spec_mode == 1 || (p->spec_mode != 0 && walkers >= kSpecMinWalkers));
+  p->spec = !p->serial_index && !p->emit_walk && (p->spec_mode >= 1 || (p->spec_mode != 0 && walkers >= kSpecMinWalkers));
   if (p->spec) {
     p->h_spec_chunks.clear();
     p->h_spec_base.assign(1, 0u);
@@ -231,6 +232,10 @@ int plan_alloc_chunks(mi_rtj_plan* p) {
       HIPCHK(c, hipMalloc((void**)&p->d_spec_base, sizeof(uint32_t) * (p->h_frames.size() + 1)));
       HIPCHK(c, hipMalloc((void**)&p->d_spec_ok, sizeof(uint32_t) * p->h_frames.size()));
       HIPCHK(c, hipMalloc((void**)&p->d_spec_todo, sizeof(uint32_t) * (p->h_frames.size() + 1)));
+      if (!p->d_spec_state) {
+        HIPCHK(c, hipMalloc((void**)&p->d_spec_state, sizeof(uint32_t) * 2));
+        HIPCHK(c, hipMemsetAsync(p->d_spec_state, 0, sizeof(uint32_t) * 2, c->stream));
+      }
       p->cap_spec_frames = (int)p->h_frames.size();
     }
     HIPCHK(c, hipMemcpyAsync(p->d_spec_chunks, p->h_spec_chunks.data(), sizeof(SpecChunkDev) * p->n_spec, hipMemcpyHostToDevice, c->stream));
@@ -273,27 +278,41 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
   } else {
     const uint32_t *todo = nullptr, *ntodo = nullptr;
     unsigned rows = (unsigned)p->n;  // grid rows of the exact kernels: one per packet, or a few that loop over the to-do list
-    if (p->spec) {
+    const bool spec = p->spec;
+    // noisy content defeats the speculation; a plan that sees every packet refused twice in a row goes
+    // without it for kSpecPauseLaunches launches.  The policy lives on the device (k_spec_policy), so it
+    // also works when launches are queued faster than they run.
+    uint32_t* const state = p->spec_mode == 1 ? nullptr : p->d_spec_state;
+    if (spec) {
       ntodo = p->d_spec_todo;
       todo = p->d_spec_todo + 1;
       rows = std::min<unsigned>(rows, kSpecFallbackRows);
       HIPCHK(c, hipMemsetAsync(p->d_spec_todo, 0, sizeof(uint32_t), c->stream));
       if ((rc = begin(MI_RTJ_K_SPEC_WALK)) != MI_RTJ_OK) return rc;
       hipLaunchKernelGGL(k_spec_walk, dim3((unsigned)((p->n_spec + 63) / 64)), dim3(64), 0, c->stream, p->d_frames,
-                         p->d_spec_chunks, (uint32_t)p->n_spec, st, c->d_lut, p->d_spec_rec, p->d_spec_nrec);
+                         p->d_spec_chunks, (uint32_t)p->n_spec, st, c->d_lut, p->d_spec_rec, p->d_spec_nrec, state);
       if ((rc = end(MI_RTJ_K_SPEC_WALK)) != MI_RTJ_OK) return rc;
       if ((rc = begin(MI_RTJ_K_SPEC_VERIFY)) != MI_RTJ_OK) return rc;
       hipLaunchKernelGGL(k_spec_verify, dim3(p->n), dim3(kSpecVerThreads), 0, c->stream, p->d_frames, p->d_spec_base, c->d_lut,
-                         p->d_spec_rec, p->d_spec_nrec, p->d_blkoff, p->d_spec_ok, p->d_spec_todo + 1, p->d_spec_todo);
+                         p->d_spec_rec, p->d_spec_nrec, p->d_blkoff, p->d_spec_ok, p->d_spec_todo + 1, p->d_spec_todo, state);
       if ((rc = end(MI_RTJ_K_SPEC_VERIFY)) != MI_RTJ_OK) return rc;
+      if (state) hipLaunchKernelGGL(k_spec_policy, dim3(1), dim3(256), 0, c->stream, (uint32_t)p->n, p->d_spec_todo, state);
     }
     if ((rc = begin(MI_RTJ_K_SUMMARIZE)) != MI_RTJ_OK) return rc;
-    if (p->one_block_type)
+    if (todo) {
+      if (p->one_block_type)
+        hipLaunchKernelGGL(k_index_summarize_todo<1>, dim3(p->max_chunks, rows), dim3(kSumThreads), 0, c->stream,
+                           p->d_frames, st, c->d_lut, p->d_summary, p->d_lentab, todo, ntodo);
+      else
+        hipLaunchKernelGGL(k_index_summarize_todo<2>, dim3(p->max_chunks, rows), dim3(kSumThreads), 0, c->stream,
+                           p->d_frames, st, c->d_lut, p->d_summary, p->d_lentab, todo, ntodo);
+    } else if (p->one_block_type) {
       hipLaunchKernelGGL(k_index_summarize<1>, dim3(p->max_chunks, rows), dim3(kSumThreads), 0, c->stream, p->d_frames,
-                         st, c->d_lut, p->d_summary, p->d_lentab, todo, ntodo);
-    else
+                         st, c->d_lut, p->d_summary, p->d_lentab);
+    } else {
       hipLaunchKernelGGL(k_index_summarize<2>, dim3(p->max_chunks, rows), dim3(kSumThreads), 0, c->stream, p->d_frames,
-                         st, c->d_lut, p->d_summary, p->d_lentab, todo, ntodo);
+                         st, c->d_lut, p->d_summary, p->d_lentab);
+    }
     if ((rc = end(MI_RTJ_K_SUMMARIZE)) != MI_RTJ_OK) return rc;
     if ((rc = begin(MI_RTJ_K_RESOLVE)) != MI_RTJ_OK) return rc;
     hipLaunchKernelGGL(k_index_resolve, dim3(todo ? std::min<unsigned>((unsigned)p->n, 1024u) : rows), dim3(256), 0, c->stream, p->d_frames, p->d_summary,
@@ -536,6 +555,7 @@ void mi_rtj_plan_destroy(mi_rtj_plan* p) {
   if (p->d_spec_rec) (void)hipFree(p->d_spec_rec);
   if (p->d_spec_nrec) (void)hipFree(p->d_spec_nrec);
   if (p->d_spec_todo) (void)hipFree(p->d_spec_todo);
+  if (p->d_spec_state) (void)hipFree(p->d_spec_state);
   if (p->d_spec_ok) (void)hipFree(p->d_spec_ok);
   delete p;
 }

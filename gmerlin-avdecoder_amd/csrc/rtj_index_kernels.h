@@ -331,20 +331,26 @@ __device__ __forceinline__ void summarize_chunk(const FrameDev* __restrict__ fra
   if (two) out[tid + kSumThreads] = s_res[s_slot[h1]];
 }
 
-// grid (chunks, frames).  With a to-do list (the packets the speculative index refused, rtj_spec_kernels.h)
-// the rows of the grid loop over that list instead.
+// grid (chunks, frames)
 template <int NT>
 __global__ __launch_bounds__(kSumThreads, MIRTJ_SUM_WAVES) void k_index_summarize(const FrameDev* __restrict__ frames,
                                                                   const uint8_t* __restrict__ stream,
                                                                   const QTab* __restrict__ lut,
                                                                   uint32_t* __restrict__ summary,
-                                                                  uint16_t* __restrict__ lentab,
-                                                                  const uint32_t* __restrict__ todo,
-                                                                  const uint32_t* __restrict__ ntodo) {
-  if (!todo) {
-    summarize_chunk<NT>(frames, stream, lut, summary, lentab, blockIdx.y);
-    return;
-  }
+                                                                  uint16_t* __restrict__ lentab) {
+  summarize_chunk<NT>(frames, stream, lut, summary, lentab, blockIdx.y);
+}
+
+// grid (chunks, rows): the rows loop over the to-do list of packets the speculative index refused
+// (rtj_spec_kernels.h).  A kernel of its own: with both forms in one kernel the direct one ran 6 % slower.
+template <int NT>
+__global__ __launch_bounds__(kSumThreads, MIRTJ_SUM_WAVES) void k_index_summarize_todo(const FrameDev* __restrict__ frames,
+                                                                       const uint8_t* __restrict__ stream,
+                                                                       const QTab* __restrict__ lut,
+                                                                       uint32_t* __restrict__ summary,
+                                                                       uint16_t* __restrict__ lentab,
+                                                                       const uint32_t* __restrict__ todo,
+                                                                       const uint32_t* __restrict__ ntodo) {
   const uint32_t n = *ntodo;
   for (uint32_t i = blockIdx.y; i < n; i += gridDim.y) {
     summarize_chunk<NT>(frames, stream, lut, summary, lentab, todo[i]);

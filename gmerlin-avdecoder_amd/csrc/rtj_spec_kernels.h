@@ -55,6 +55,7 @@ struct SpecChunkDev {
   uint32_t c;      // chunk number within the packet
 };
 constexpr int kSpecFallbackRows = 64;
+constexpr int kSpecPauseLaunches = 64;  // launches a plan goes without speculation after two in which every packet was refused
 #ifndef MIRTJ_SPEC_VER_THREADS
 #define MIRTJ_SPEC_VER_THREADS 1024
 #endif
@@ -64,8 +65,9 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
                                                    const SpecChunkDev* __restrict__ chunks, uint32_t total,
                                                    const uint8_t* __restrict__ stream,
                                                    const QTab* __restrict__ lut, uint16_t* __restrict__ records,
-                                                   uint32_t* __restrict__ nrec) {
+                                                   uint32_t* __restrict__ nrec, const uint32_t* __restrict__ state) {
   __shared__ __attribute__((aligned(16))) uint8_t s_tile[64 * kSpecRow];
+  if (state && state[1]) return;  // paused (k_spec_policy)
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[64 * kSpecRingRow];
   const int lane = threadIdx.x;
   const uint32_t g = blockIdx.x * 64u + (uint32_t)lane;
@@ -186,7 +188,11 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
                                                       const uint16_t* __restrict__ records,
                                                       const uint32_t* __restrict__ nrec, uint32_t* __restrict__ blkoff,
                                                       uint32_t* __restrict__ ok, uint32_t* __restrict__ todo,
-                                                      uint32_t* __restrict__ ntodo) {
+                                                      uint32_t* __restrict__ ntodo, const uint32_t* __restrict__ state) {
+  if (state && state[1]) {  // paused (k_spec_policy): nothing was walked, nothing is proven
+    if (threadIdx.x == 0) ok[blockIdx.x] = 0;
+    return;
+  }
   __shared__ uint32_t s_e[kSpecVerThreads], s_wave[kSpecVerThreads / 64], s_carry[3];  // carry: exit of the last chunk so far, blocks so far, bad
   __shared__ uint32_t s_i0[kSpecVerThreads], s_base[kSpecVerThreads], s_cnt[kSpecVerThreads];
   const FrameDev f = frames[blockIdx.x];
@@ -277,6 +283,26 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
     const uint32_t good = (!s_carry[2] && s_carry[1] >= last + 1u) ? 1u : 0u;
     ok[blockIdx.x] = good;
     if (!good) todo[atomicAdd(ntodo, 1u)] = blockIdx.x;
+  }
+}
+
+// After k_spec_verify, one workgroup.  todo_cnt[0] = packets refused in this launch, todo_cnt[1..] = the list;
+// state[0] = launches in a row that refused everything, state[1] = launches left without speculation.
+// While paused k_spec_walk and k_spec_verify return at once and this kernel puts every packet on the list.
+__global__ __launch_bounds__(256) void k_spec_policy(uint32_t n, uint32_t* __restrict__ todo_cnt, uint32_t* __restrict__ state) {
+  const uint32_t pause = state[1];
+  if (pause) {
+    for (uint32_t i = threadIdx.x; i < n; i += 256) todo_cnt[1 + i] = i;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      todo_cnt[0] = n;
+      state[1] = pause - 1u;
+      if (pause == 1u) state[0] = 1u;  // one more launch that refuses everything pauses again
+    }
+  } else if (threadIdx.x == 0) {
+    const uint32_t streak = todo_cnt[0] == n ? state[0] + 1u : 0u;
+    state[0] = streak;
+    if (streak >= 2u) state[1] = (uint32_t)kSpecPauseLaunches;
   }
 }
 

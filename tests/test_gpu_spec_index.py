@@ -83,3 +83,41 @@ def test_speculation_is_taken_or_refused_as_expected(dev):
         plan.close()
         dev.free(d_stream)
         dev.free(d_out)
+
+
+def test_plans_that_keep_being_refused_pause_the_speculation(monkeypatch):
+    """Device-side policy (k_spec_policy): after two launches in which every packet was refused the
+    walkers return at once for a while; results do not change.  MI_RTJ_SPEC=2 switches the speculation
+    on regardless of the batch size but, unlike =1, leaves the policy active."""
+    monkeypatch.setenv("MI_RTJ_SPEC", "2")
+    d = P.MiRtj()
+    w, h, n = 640, 368, 300000
+    rng = np.random.default_rng(3)
+    total = 12 + n
+    hdr = np.array([total & 255, (total >> 8) & 255, (total >> 16) & 255, 0, 12, 0, w & 255, w >> 8, h & 255, h >> 8, 200, 0], np.uint8)
+    pkts = [np.concatenate([hdr, rng.integers(0, 256, n, dtype=np.uint8)]) for _ in range(3)]
+    d_stream, po, pl, hdrs = d.upload_packets(pkts, align=1)
+    fsz = T.frame_bytes(w, h)
+    d_out = d.alloc(fsz * len(pkts))
+    plan = d.plan(hdrs, po, pl, np.arange(len(pkts), dtype=np.uint64) * np.uint64(fsz))
+    dec = R.OracleDecoder()
+    want = []
+    for p in pkts:
+        x = np.zeros(fsz, np.uint8)
+        dec.decode(p, x)
+        want.append(x)
+    walk = []
+    for it in range(6):
+        d.memset(d_out, 0, fsz * len(pkts))
+        plan.profile(True)
+        plan.decode(d_stream, d_out)
+        ms, _ = plan.times()
+        walk.append(ms["k_spec_walk"])
+        assert plan.spec_stats()[0] == 0
+        for i in range(len(pkts)):
+            assert np.array_equal(d.d2h(d_out, fsz, offset=i * fsz), want[i]), (it, i)
+    assert min(walk[:2]) > 5 * max(walk[2:]), walk
+    plan.close()
+    d.free(d_stream)
+    d.free(d_out)
+    d.close()
