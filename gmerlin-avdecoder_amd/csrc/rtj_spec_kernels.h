@@ -30,7 +30,7 @@
 #include "rtj_decode_kernels.h"
 
 #ifndef MIRTJ_SPEC_CHUNK
-#define MIRTJ_SPEC_CHUNK 3584
+#define MIRTJ_SPEC_CHUNK 2560
 #endif
 #ifndef MIRTJ_SPEC_LEAD
 #define MIRTJ_SPEC_LEAD 512
@@ -43,7 +43,8 @@ constexpr int kSpecLead = MIRTJ_SPEC_LEAD;   // bytes it parses before them, fro
 constexpr int kSpecTail = 512;    // and after them: the next macroblock start is within 6 * 64 bytes
 constexpr int kSpecSpan = kSpecLead + kSpecChunk + kSpecTail;
 constexpr int kSpecTile = 128;    // bytes per lane fetched at a time (one cache line)
-constexpr int kSpecCap = 1024;    // block starts a walker can record (16-bit, relative to its first byte)
+constexpr int kSpecCap = 2048;    // block starts a walker can record (16-bit, relative to its first byte):
+                                  // enough for blocks of 1.75 bytes on average over its span
 constexpr uint64_t kSpecMinWalkers = 8192;  // below this the exact kernels index a batch faster (host policy)
 constexpr int kSpecRingRow = 64 + 16;       // LDS bytes per lane of the record ring: 32 records + bank padding
 constexpr int kSpecRow = kSpecTile + 16;  // LDS bytes per lane: tile + the dword after it + bank padding
@@ -66,7 +67,6 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
                                                    const uint8_t* __restrict__ stream,
                                                    const QTab* __restrict__ lut, uint16_t* __restrict__ records,
                                                    uint32_t* __restrict__ nrec, const uint32_t* __restrict__ state) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_tile[64 * kSpecRow];
   if (state && state[1]) return;  // paused (k_spec_policy)
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[64 * kSpecRingRow];
   const int lane = threadIdx.x;
@@ -81,7 +81,6 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
   const uint32_t* g4 = (const uint32_t*)(gp - sh);
   // bytes of the packet from g4[0] on (start < data_len for every chunk but an empty packet's only one)
   const int avail = (int)f.data_len - (int)start + (int)sh;
-  uint8_t* my = s_tile + lane * kSpecRow;
 
   // ---- one tile = 32 dwords + the one after them (for the funnel shift), bytes past the packet read 0 ----
   uint32_t buf[33];
@@ -132,18 +131,18 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
 
   request(0);
   for (int t = 0; t < kSpecSpan / kSpecTile; t++) {
-    {
-      uint4* row = (uint4*)my;
+    // the tile is parsed out of registers (fully unrolled: 128 byte steps); staging it in LDS for a
+    // smaller loop body capped the kernel at 11 waves per CU
+    uint32_t cur[33];
 #pragma unroll
-      for (int k = 0; k < 8; k++) row[k] = make_uint4(buf[4 * k], buf[4 * k + 1], buf[4 * k + 2], buf[4 * k + 3]);
-      *(uint32_t*)(my + kSpecTile) = buf[32];
-    }
+    for (int k = 0; k < 33; k++) cur[k] = buf[k];
     if (t + 1 < kSpecSpan / kSpecTile) request(t + 1);  // in flight while this tile is parsed
+#pragma unroll
     for (int i = 0; i < kSpecTile / 16; i++) {
-      const uint4 q = *(const uint4*)(my + 16 * i);
-      const uint32_t q4 = *(const uint32_t*)(my + 16 * i + 16);
-      const uint32_t wd[4] = {__builtin_amdgcn_alignbyte(q.y, q.x, sh), __builtin_amdgcn_alignbyte(q.z, q.y, sh),
-                              __builtin_amdgcn_alignbyte(q.w, q.z, sh), __builtin_amdgcn_alignbyte(q4, q.w, sh)};
+      const uint32_t wd[4] = {__builtin_amdgcn_alignbyte(cur[4 * i + 1], cur[4 * i], sh),
+                              __builtin_amdgcn_alignbyte(cur[4 * i + 2], cur[4 * i + 1], sh),
+                              __builtin_amdgcn_alignbyte(cur[4 * i + 3], cur[4 * i + 2], sh),
+                              __builtin_amdgcn_alignbyte(cur[4 * i + 4], cur[4 * i + 3], sh)};
       const uint32_t pos = (uint32_t)(t * kSpecTile + 16 * i);  // walker-relative position of wd's first byte
 #pragma unroll
       for (int b = 0; b < 16; b++) {
