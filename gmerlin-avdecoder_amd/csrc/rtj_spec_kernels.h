@@ -10,13 +10,15 @@
 //
 //   k_spec_walk    one LANE per chunk: starts kSpecLead bytes before its chunk, assuming a macroblock
 //                  starts there, and runs RTjpeg_s2b's length rule (lib/RTjpeg.c:157-186, 2704) as a
-//                  byte-serial state machine over lead + chunk + tail, recording every block start.
+//                  byte-serial state machine over lead + chunk, recording every block start.
 //                  64 chunks advance in lockstep per wave: ~20 vector instructions per byte for 64
 //                  streams, against ~20 per BLOCK POSITION AND TYPE in k_index_summarize.
-//   k_spec_verify  per packet: the first (macro)block start a walker saw inside its chunk must be the
-//                  first one its predecessor saw past ITS chunk, and chunk 0 starts at byte 0.  By
-//                  induction every walker is then on the true chain from that point on, so the check
-//                  is exact, not a heuristic: it either proves the whole packet's index or rejects it.
+//   k_spec_verify  per packet: the last (macro)block start a walker saw in its lead, i.e. before its
+//                  chunk, must also be a (macro)block start of its predecessor, whose own span ends
+//                  there; chunk 0 starts at byte 0.  Two walkers that stand on the same byte in the same
+//                  phase go on alike, so by induction every walker is on the true chain from that
+//                  hand-over point on: the check is exact, not a heuristic — it either proves the whole
+//                  packet's index or rejects it.
 //                  Also counts blocks per chunk (prefix sums -> global block numbers) and turns the
 //                  recorded starts into the block-offset index k_decode reads.
 //
@@ -33,15 +35,14 @@
 #define MIRTJ_SPEC_CHUNK 2560
 #endif
 #ifndef MIRTJ_SPEC_LEAD
-#define MIRTJ_SPEC_LEAD 512
+#define MIRTJ_SPEC_LEAD 768
 #endif
 
 namespace mirtj {
 
 constexpr int kSpecChunk = MIRTJ_SPEC_CHUNK;  // stream bytes a walker owns
 constexpr int kSpecLead = MIRTJ_SPEC_LEAD;   // bytes it parses before them, from an assumed macroblock start
-constexpr int kSpecTail = 512;    // and after them: the next macroblock start is within 6 * 64 bytes
-constexpr int kSpecSpan = kSpecLead + kSpecChunk + kSpecTail;
+constexpr int kSpecSpan = kSpecLead + kSpecChunk;
 constexpr int kSpecTile = 128;    // bytes per lane fetched at a time (one cache line)
 constexpr int kSpecCap = 2048;    // block starts a walker can record (16-bit, relative to its first byte):
                                   // enough for blocks of 1.75 bytes on average over its span
@@ -49,7 +50,7 @@ constexpr uint64_t kSpecMinWalkers = 8192;  // below this the exact kernels inde
 constexpr int kSpecRingRow = 64 + 16;       // LDS bytes per lane of the record ring: 32 records + bank padding
 constexpr int kSpecRow = kSpecTile + 16;  // LDS bytes per lane: tile + the dword after it + bank padding
 static_assert(kSpecSpan % kSpecTile == 0 && kSpecSpan < 65536, "walker span: whole tiles, 16-bit positions");
-static_assert(kSpecTail >= 6 * 64 + 64, "a walker must reach the first macroblock start past its chunk");
+static_assert(kSpecLead >= 6 * 64 + 64, "the lead must hold at least one whole macroblock");
 
 struct SpecChunkDev {
   uint32_t frame;  // index into the plan's frames
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
     if (threadIdx.x == 0) ok[blockIdx.x] = 0;
     return;
   }
-  __shared__ uint32_t s_e[kSpecVerThreads], s_wave[kSpecVerThreads / 64], s_carry[3];  // carry: exit of the last chunk so far, blocks so far, bad
+  __shared__ uint32_t s_wave[kSpecVerThreads / 64], s_carry[3];  // carry: [1] blocks so far, [2] bad
   __shared__ uint32_t s_i0[kSpecVerThreads], s_base[kSpecVerThreads], s_cnt[kSpecVerThreads];
   const FrameDev f = frames[blockIdx.x];
   const uint32_t sc0 = spec_base[blockIdx.x], nsc = spec_base[blockIdx.x + 1] - sc0;
@@ -204,35 +205,38 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
   const uint32_t last = 6u * f.nmb;  // the index holds one entry past the last block: the end position
   uint32_t* const out = blkoff + f.blk_base;
   if (tid == 0) {
-    s_carry[0] = 0;  // chunk 0 must start at byte 0
     s_carry[1] = 0;
     s_carry[2] = 0;
   }
   __syncthreads();
   for (uint32_t c0 = 0; c0 < nsc; c0 += kSpecVerThreads) {
     const uint32_t c = c0 + (uint32_t)tid;
-    uint32_t gpos = 0, epos = 0, cnt = 0, i0 = 0, bad = 0;
+    uint32_t cnt = 0, i0 = 0, bad = 0;
     if (c < nsc) {
+      // where chunk c takes over: the last unit-aligned record of its walker before the chunk (record 0,
+      // the walker's arbitrary first byte, if it saw no other: the match below then fails)
+      auto take_over = [&](uint32_t cc, uint32_t& start, uint32_t& idx) {
+        const uint32_t n = min(nrec[sc0 + cc], (uint32_t)kSpecCap);
+        const uint16_t* R = records + (size_t)(sc0 + cc) * kSpecCap;
+        start = cc * (uint32_t)kSpecChunk - (uint32_t)kSpecLead;
+        idx = (spec_lower_bound(R, n, (uint32_t)kSpecLead) - 1u) / unit * unit;
+        return start + R[idx];
+      };
       const uint32_t full = nrec[sc0 + c], n = min(full, (uint32_t)kSpecCap);
       const uint16_t* R = records + (size_t)(sc0 + c) * kSpecCap;
-      const uint32_t start = c ? c * (uint32_t)kSpecChunk - (uint32_t)kSpecLead : 0u, loff = c ? (uint32_t)kSpecLead : 0u;
+      uint32_t start = 0;
       bad = full > (uint32_t)kSpecCap;  // the walker ran out of slots
-      i0 = (spec_lower_bound(R, n, loff) + unit - 1u) / unit * unit;
+      if (c) (void)take_over(c, start, i0);
       uint32_t i1 = n;  // the packet's last walker: everything it saw (bytes past the packet read as 0)
-      if (c + 1 < nsc) i1 = (spec_lower_bound(R, n, loff + (uint32_t)kSpecChunk) + unit - 1u) / unit * unit;
-      if (i0 >= n || (c + 1 < nsc && i1 >= n)) bad = 1;
-      else {
-        gpos = start + R[i0];
-        epos = c + 1 < nsc ? start + R[i1] : 0u;
-        cnt = i1 - i0;
+      if (c + 1 < nsc) {
+        if (nrec[sc0 + c + 1] > (uint32_t)kSpecCap) bad = 1;
+        uint32_t sn, in;
+        const uint32_t h = take_over(c + 1, sn, in);  // absolute position of the hand-over to chunk c + 1
+        i1 = spec_lower_bound(R, n, h - start);
+        if (i1 >= n || start + R[i1] != h || i1 % unit != 0u) bad = 1;  // not a (macro)block start of mine
       }
-    }
-    // chain check against the predecessor's exit
-    s_e[tid] = epos;
-    __syncthreads();
-    if (c < nsc) {
-      const uint32_t prev = tid ? s_e[tid - 1] : s_carry[0];
-      if (gpos != prev) bad = 1;
+      if (bad || i1 < i0) bad = 1;
+      else cnt = i1 - i0;
     }
     // blocks before this chunk: scan over the tile + carry
     const uint32_t incl = wave_incl_scan(cnt);
@@ -246,10 +250,7 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
     s_cnt[tid] = cnt;
     __syncthreads();
     if (lane == 0 && anybad) atomicOr(&s_carry[2], 1u);
-    if (tid == kSpecVerThreads - 1) {
-      s_carry[0] = epos;
-      s_carry[1] = before + cnt;
-    }
+    if (tid == kSpecVerThreads - 1) s_carry[1] = before + cnt;
     // recorded starts -> block offsets, one wave per chunk of the tile (harmless if the packet fails later:
     // counts of refused chunks are 0, everything is clipped to the packet's own index, and the exact
     // kernels rewrite it)
