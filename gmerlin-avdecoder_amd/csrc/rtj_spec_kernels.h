@@ -46,7 +46,8 @@ constexpr int kSpecSpan = kSpecLead + kSpecChunk;
 constexpr int kSpecTile = 128;    // bytes per lane fetched at a time (one cache line)
 constexpr int kSpecCap = 2048;    // block starts a walker can record (16-bit, relative to its first byte):
                                   // enough for blocks of 1.75 bytes on average over its span
-constexpr uint64_t kSpecMinWalkers = 8192;  // below this the exact kernels index a batch faster (host policy)
+constexpr uint64_t kSpecMinWalkers = 40000;  // below this (~100 MB of packets) the exact kernels index a batch faster:
+                                            // a walker is one lane and runs ~0.35 ms whatever the batch (host policy)
 constexpr int kSpecRingRow = 64 + 16;       // LDS bytes per lane of the record ring: 32 records + bank padding
 constexpr int kSpecRow = kSpecTile + 16;  // LDS bytes per lane: tile + the dword after it + bank padding
 static_assert(kSpecSpan % kSpecTile == 0 && kSpecSpan < 65536, "walker span: whole tiles, 16-bit positions");
