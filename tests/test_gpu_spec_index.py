@@ -121,3 +121,26 @@ def test_plans_that_keep_being_refused_pause_the_speculation(monkeypatch):
     d.free(d_stream)
     d.free(d_out)
     d.close()
+
+
+def test_many_refused_packets_loop_over_the_todo_rows(dev):
+    """More refused packets than the exact kernels have grid rows (64), mixed with provable ones, in
+    one plan: the rows loop over the to-do list; every index and picture equals the oracle's."""
+    rng = np.random.default_rng(11)
+    w, h = 160, 64
+    good_enc = R.OracleEncoder(w, h, 255)
+    pkts = []
+    for i in range(200):
+        if i % 4 == 3:
+            pkts.append(good_enc.encode(R.synth_frame(w, h, i, amp=6)))
+        else:
+            n = int(rng.integers(200, 9000))
+            total = 12 + n
+            hdr = np.array([total & 255, (total >> 8) & 255, 0, 0, 12, 0, w & 255, w >> 8, h & 255, h >> 8, 255, 0], np.uint8)
+            pkts.append(np.concatenate([hdr, rng.integers(0, 256, n, dtype=np.uint8)]))
+    outs = T.batch_decode(dev, pkts, prefill=0x11)
+    dec = R.OracleDecoder()
+    for i, (p, got) in enumerate(zip(pkts, outs)):
+        want = np.full(T.frame_bytes(w, h), 0x11, np.uint8)
+        dec.decode(p, want)
+        assert T.first_diff(got, want) is None, i
