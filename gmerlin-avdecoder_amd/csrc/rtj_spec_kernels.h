@@ -8,7 +8,7 @@
 // and the final zero run of a block covers them whatever the count was before — and, when luma and
 // chroma blocks carry different numbers of raw bytes, into step with the macroblock phase as well.
 //
-//   k_spec_walk    one LANE per chunk: starts kSpecLead bytes before its chunk, assuming a macroblock
+//   k_spec_walk    one LANE per chunk (2048 bytes): starts kSpecLead bytes before its chunk, assuming a macroblock
 //                  starts there, and runs RTjpeg_s2b's length rule (lib/RTjpeg.c:157-186, 2704) as a
 //                  byte-serial state machine over lead + chunk, recording every block start.
 //                  64 chunks advance in lockstep per wave: ~20 vector instructions per byte for 64
@@ -32,7 +32,7 @@
 #include "rtj_decode_kernels.h"
 
 #ifndef MIRTJ_SPEC_CHUNK
-#define MIRTJ_SPEC_CHUNK 2560
+#define MIRTJ_SPEC_CHUNK 2048
 #endif
 #ifndef MIRTJ_SPEC_LEAD
 #define MIRTJ_SPEC_LEAD 768
@@ -63,6 +63,39 @@ constexpr int kSpecPauseLaunches = 64;  // launches a plan goes without speculat
 #define MIRTJ_SPEC_VER_THREADS 1024
 #endif
 constexpr int kSpecVerThreads = MIRTJ_SPEC_VER_THREADS;  // k_spec_verify: chunks of a packet handled side by side  // grid rows of the exact kernels when they only serve refused packets
+
+// One byte of the walker's state machine, spelled out: 17 vector instructions (the compiler's version of
+// the same C++ had 21-22: it keeps lane masks as 0/1 integers and splits the counters).  State: u = units
+// of the current block so far, q = 5 - (block number within the macroblock), rb = DC + raw bytes of the
+// current block's type, cnt = records so far, em = lane mask "the previous byte ended a block".  The next
+// block's start `val` goes to ring slot cnt % 32 on every byte; cnt only moves on when this byte ends its
+// block.  gfx950 wants two instructions between a vector compare and the use of its mask; the order below
+// provides them without s_nop.
+#define MIRTJ_SPEC_STEP(SEL)                                                                                      \
+  asm("v_sub_u32_sdwa %[t], sext(%[w]), %[k63] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SEL               \
+      " src1_sel:DWORD\n\t"                                                                                       \
+      "v_cmp_eq_i32_e32 vcc, %[kn64], %[t]\n\t"         /* the byte is 0xFF */                                     \
+      "v_cmp_lt_i32_e64 %[ma], %[u], %[rb]\n\t"         /* a DC or raw byte */                                     \
+      "v_max_i32_e32 %[wt], 1, %[t]\n\t"                /* token weight (lib/RTjpeg.c:171-182) */                  \
+      "s_and_b64 vcc, vcc, %[em]\n\t"                   /* 0xFF as a block's first byte: one-byte block */        \
+      "v_bfe_u32 %[idx], %[cnt], 0, 5\n\t"                                                                         \
+      "v_cndmask_b32_e64 %[wr], 1, 64, vcc\n\t"                                                                    \
+      "v_cndmask_b32_e64 %[wt], %[wt], %[wr], %[ma]\n\t"                                                           \
+      "v_add_u32_e32 %[u], %[u], %[wt]\n\t"                                                                        \
+      "v_cmp_lt_i32_e64 %[em], 63, %[u]\n\t"            /* 64 units: the block ends with this byte */              \
+      "v_lshl_add_u32 %[ra], %[idx], 1, %[ring]\n\t"                                                               \
+      "ds_write_b16 %[ra], %[val]\n\t"                                                                             \
+      "v_subb_co_u32_e64 %[q], vcc, %[q], 0, %[em]\n\t"                                                            \
+      "v_cmp_lt_i32_e64 %[mx], %[q], 0\n\t"             /* past the macroblock's last block */                     \
+      "v_cmp_lt_u32_e64 %[my], %[q], 2\n\t"             /* a chroma block is next */                               \
+      "v_addc_co_u32_e64 %[cnt], vcc, 0, %[cnt], %[em]\n\t"                                                        \
+      "v_cndmask_b32_e64 %[u], %[u], 0, %[em]\n\t"                                                                 \
+      "v_cndmask_b32_e64 %[q], %[q], 5, %[mx]\n\t"                                                                 \
+      "v_cndmask_b32_e64 %[rb], %[lb], %[cb], %[my]"                                                               \
+      : [u] "+v"(u), [cnt] "+v"(cnt), [q] "+v"(q), [rb] "+v"(rb), [em] "+s"(em), [t] "=&v"(t_), [wt] "=&v"(wt_),  \
+        [wr] "=&v"(wr_), [idx] "=&v"(idx_), [ra] "=&v"(ra_), [ma] "=&s"(ma_), [mx] "=&s"(mx_), [my] "=&s"(my_)     \
+      : [w] "v"(w_), [k63] "v"(k63), [kn64] "v"(kn64), [ring] "v"(ring_a), [val] "v"(val_), [lb] "v"(lb), [cb] "v"(cb) \
+      : "vcc", "memory")
 
 __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ frames,
                                                    const SpecChunkDev* __restrict__ chunks, uint32_t total,
@@ -108,8 +141,9 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
   // ---- the length rule as a branch-free state machine.  A block is complete after 64 units: DC and the
   //      raw bytes count 1 each, a token its weight.  u = units of the current block so far, rb = its
   //      1 + bt8 DC/raw bytes, ph = its number within the macroblock ----
-  int u = 0;
-  uint32_t ph = 0;
+  int u = 0, rb = lb;
+  uint32_t q = 5;        // 5 - block number within the macroblock
+  uint64_t em = ~0ull;   // the walker's first byte is taken to be a macroblock's first
   // record k = start of the walker's block k (phase k mod 6), 16-bit.  Records are staged in a 32-entry
   // ring per lane in LDS and leave for HBM eight at a time (one 16-byte store): a 2-byte global store
   // per block end was 40 % of the kernel.  Idle lanes of the last wave own the spare row after the last
@@ -117,6 +151,8 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
   const uint32_t row0 = 2u * (act ? g : total) * (uint32_t)kSpecCap;
   uint8_t* const rec8 = (uint8_t*)records;
   uint8_t* const ring = s_ring + lane * kSpecRingRow;
+  const uint32_t ring_a = lds_address(ring);
+  const int kn64 = -64;
   uint32_t cnt = 1, flushed = 0;
   *(uint16_t*)ring = 0;
   const int k63 = 63;
@@ -148,19 +184,16 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
       const uint32_t pos = (uint32_t)(t * kSpecTile + 16 * i);  // walker-relative position of wd's first byte
 #pragma unroll
       for (int b = 0; b < 16; b++) {
-        const int t63 = sbyte_minus(wd[b >> 2], b & 3, k63);  // (int8)byte - 63; 0xFF -> -64
-        const int rb = ph < 4u ? lb : cb;
-        int wt = max(t63, 1);                                 // token weight (lib/RTjpeg.c:171-182)
-        if (u < rb) wt = (u == 0 && t63 == -64) ? 64 : 1;     // DC/raw byte; first byte 0xFF: one-byte block
-        u += wt;
-        // the next block would start at pos + b + 1: written to the ring's next slot every time, kept
-        // (the slot counter moves on) only when this byte ends its block
-        *(uint16_t*)(ring + ((cnt & 31u) << 1)) = (uint16_t)(pos + (uint32_t)b + 1u);
-        const bool end = u >= 64;
-        cnt += end ? 1u : 0u;
-        ph += end ? 1u : 0u;
-        ph = ph == 6u ? 0u : ph;
-        u = end ? 0 : u;
+        const uint32_t w_ = wd[b >> 2], val_ = pos + (uint32_t)b + 1u;  // the next block would start at pos + b + 1
+        int t_, wt_, wr_;
+        uint32_t idx_, ra_;
+        uint64_t ma_, mx_, my_;
+        switch (b & 3) {
+          case 0: MIRTJ_SPEC_STEP("BYTE_0"); break;
+          case 1: MIRTJ_SPEC_STEP("BYTE_1"); break;
+          case 2: MIRTJ_SPEC_STEP("BYTE_2"); break;
+          default: MIRTJ_SPEC_STEP("BYTE_3"); break;
+        }
       }
       flush(8);  // at most 7 + 16 records are staged at this point
     }
