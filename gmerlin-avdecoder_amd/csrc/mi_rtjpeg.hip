@@ -80,6 +80,9 @@ struct mi_rtj_plan {
   uint32_t* d_spec_base = nullptr;
   uint16_t* d_spec_rec = nullptr;          // [walkers][kSpecCap]
   uint32_t* d_spec_nrec = nullptr;
+  uint32_t* d_spec_wstart = nullptr;       // [walkers]: first byte each walker parsed (repairs move it)
+  uint2* d_spec_fix = nullptr;             // [walkers]: (walker, byte to start from) of the chunks to walk again
+  uint32_t* d_spec_nfix = nullptr;
   uint32_t* d_spec_ok = nullptr;           // [n]: 1 = the packet's index is proven
   uint32_t* d_spec_todo = nullptr;         // [n + 1]: count, then the packets left to the exact kernels
   int cap_spec_frames = 0;
@@ -215,11 +218,16 @@ int plan_alloc_chunks(mi_rtj_plan* p) {
         (void)hipFree(p->d_spec_chunks);
         (void)hipFree(p->d_spec_rec);
         (void)hipFree(p->d_spec_nrec);
+        (void)hipFree(p->d_spec_wstart);
+        (void)hipFree(p->d_spec_fix);
         p->d_spec_chunks = nullptr;
       }
       HIPCHK(c, hipMalloc((void**)&p->d_spec_chunks, sizeof(SpecChunkDev) * p->n_spec));
       HIPCHK(c, hipMalloc((void**)&p->d_spec_rec, sizeof(uint16_t) * kSpecCap * (p->n_spec + 1)));  // + a spare row for idle lanes
       HIPCHK(c, hipMalloc((void**)&p->d_spec_nrec, sizeof(uint32_t) * p->n_spec));
+      HIPCHK(c, hipMalloc((void**)&p->d_spec_wstart, sizeof(uint32_t) * p->n_spec));
+      HIPCHK(c, hipMalloc((void**)&p->d_spec_fix, sizeof(uint2) * p->n_spec));
+      if (!p->d_spec_nfix) HIPCHK(c, hipMalloc((void**)&p->d_spec_nfix, sizeof(uint32_t)));
       p->cap_spec = p->n_spec;
     }
     if ((int)p->h_frames.size() > p->cap_spec_frames) {
@@ -288,15 +296,24 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
       todo = p->d_spec_todo + 1;
       rows = std::min<unsigned>(rows, kSpecFallbackRows);
       HIPCHK(c, hipMemsetAsync(p->d_spec_todo, 0, sizeof(uint32_t), c->stream));
+      HIPCHK(c, hipMemsetAsync(p->d_spec_nfix, 0, sizeof(uint32_t), c->stream));
       if ((rc = begin(MI_RTJ_K_SPEC_WALK)) != MI_RTJ_OK) return rc;
       hipLaunchKernelGGL(k_spec_walk, dim3((unsigned)((p->n_spec + 63) / 64)), dim3(64), 0, c->stream, p->d_frames,
-                         p->d_spec_chunks, (uint32_t)p->n_spec, st, c->d_lut, p->d_spec_rec, p->d_spec_nrec, state);
+                         p->d_spec_chunks, (uint32_t)p->n_spec, st, c->d_lut, p->d_spec_rec, p->d_spec_nrec, p->d_spec_wstart, state);
       if ((rc = end(MI_RTJ_K_SPEC_WALK)) != MI_RTJ_OK) return rc;
       if ((rc = begin(MI_RTJ_K_SPEC_VERIFY)) != MI_RTJ_OK) return rc;
+      // first pass; walkers that had not fallen into step are walked again from a known block start; second
+      // pass over the packets concerned (both return at once when there is nothing to repair)
       hipLaunchKernelGGL(k_spec_verify, dim3(p->n), dim3(kSpecVerThreads), 0, c->stream, p->d_frames, p->d_spec_base, c->d_lut,
-                         p->d_spec_rec, p->d_spec_nrec, p->d_blkoff, p->d_spec_ok, p->d_spec_todo + 1, p->d_spec_todo, state);
+                         p->d_spec_rec, p->d_spec_nrec, p->d_blkoff, p->d_spec_ok, p->d_spec_todo + 1, p->d_spec_todo, state,
+                         p->d_spec_wstart, p->d_spec_fix, p->d_spec_nfix, 1);
+      hipLaunchKernelGGL(k_spec_repair, dim3(kSpecRepairGrid), dim3(64), 0, c->stream, p->d_frames, p->d_spec_chunks, st,
+                         c->d_lut, p->d_spec_rec, p->d_spec_nrec, p->d_spec_wstart, p->d_spec_fix, p->d_spec_nfix);
+      hipLaunchKernelGGL(k_spec_verify, dim3(p->n), dim3(kSpecVerThreads), 0, c->stream, p->d_frames, p->d_spec_base, c->d_lut,
+                         p->d_spec_rec, p->d_spec_nrec, p->d_blkoff, p->d_spec_ok, p->d_spec_todo + 1, p->d_spec_todo, state,
+                         p->d_spec_wstart, p->d_spec_fix, p->d_spec_nfix, 2);
       if ((rc = end(MI_RTJ_K_SPEC_VERIFY)) != MI_RTJ_OK) return rc;
-      if (state) hipLaunchKernelGGL(k_spec_policy, dim3(1), dim3(256), 0, c->stream, (uint32_t)p->n, p->d_spec_todo, state);
+      if (state) hipLaunchKernelGGL(k_spec_policy, dim3(1), dim3(256), 0, c->stream, (uint32_t)p->n, (uint32_t)p->n_spec, p->d_spec_todo, p->d_spec_nfix, state);
     }
     if ((rc = begin(MI_RTJ_K_SUMMARIZE)) != MI_RTJ_OK) return rc;
     if (todo) {
@@ -554,6 +571,9 @@ void mi_rtj_plan_destroy(mi_rtj_plan* p) {
   if (p->d_spec_base) (void)hipFree(p->d_spec_base);
   if (p->d_spec_rec) (void)hipFree(p->d_spec_rec);
   if (p->d_spec_nrec) (void)hipFree(p->d_spec_nrec);
+  if (p->d_spec_wstart) (void)hipFree(p->d_spec_wstart);
+  if (p->d_spec_fix) (void)hipFree(p->d_spec_fix);
+  if (p->d_spec_nfix) (void)hipFree(p->d_spec_nfix);
   if (p->d_spec_todo) (void)hipFree(p->d_spec_todo);
   if (p->d_spec_state) (void)hipFree(p->d_spec_state);
   if (p->d_spec_ok) (void)hipFree(p->d_spec_ok);
@@ -608,7 +628,7 @@ int mi_rtj_plan_spec_stats(mi_rtj_plan* p, int* proven, long long* walkers) {
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemcpyAsync(ok.data(), p->d_spec_ok, sizeof(uint32_t) * p->n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  for (uint32_t v : ok) *proven += v ? 1 : 0;
+  for (uint32_t v : ok) *proven += v == 1u ? 1 : 0;
   return MI_RTJ_OK;
 }
 

@@ -124,6 +124,74 @@ __device__ __forceinline__ void walk_blocks(const FrameDev& f, const uint8_t* __
   }
 }
 
+// The same walk, bounded by position instead of block count, for the speculative index's repairs
+// (rtj_spec_kernels.h): from byte p_start, taken to start a macroblock, every block start below `limit` is
+// recorded as a 16-bit offset from p_start (the first record is 0).  Returns the number of blocks seen;
+// only the first `cap` are stored.
+__device__ __forceinline__ uint32_t walk_record(const FrameDev& f, const uint8_t* __restrict__ stream,
+                                                const QTab* __restrict__ lut, uint32_t p_start, uint32_t limit,
+                                                uint16_t* __restrict__ out, uint32_t cap) {
+  const int lane = threadIdx.x & 63;
+  const uint8_t* g = stream + f.data_off;
+  const uint32_t len = f.data_len;
+  const uint32_t lb8 = (uint32_t)lut[f.qidx].lb8, cb8 = (uint32_t)lut[f.qidx].cb8;
+  auto fetch = [&](uint32_t pos) -> uint32_t {
+    const uint32_t i = pos + lane;
+    return i < len ? (uint32_t)g[i] : 0u;
+  };
+  uint32_t base = p_start;
+  uint32_t cur = fetch(base), nxt = fetch(base + 64u), pf1 = fetch(base + 128u), pf2 = fetch(base + 192u),
+           pf3 = fetch(base + 256u);
+  uint32_t Wc = wave_incl_scan(token_weight(cur));
+  uint32_t Wn = wave_incl_scan(token_weight(nxt)) + (uint32_t)__builtin_amdgcn_readlane((int)Wc, 63);
+  uint32_t p = p_start, ph = 0, acc = 0, k = 0;
+  while (p < limit) {
+    while (p - base >= 64u) {  // slide the two windows forward
+      base += 64u;
+      cur = nxt;
+      Wc = Wn;
+      nxt = pf1;
+      pf1 = pf2;
+      pf2 = pf3;
+      pf3 = fetch(base + 256u);
+      Wn = wave_incl_scan(token_weight(nxt)) + (uint32_t)__builtin_amdgcn_readlane((int)Wc, 63);
+    }
+    acc = (uint32_t)lane == (k & 63u) ? p - p_start : acc;
+    if ((k & 63u) == 63u) {
+      const uint32_t idx = (k & ~63u) + (uint32_t)lane;
+      if (idx < cap) out[idx] = (uint16_t)acc;
+    }
+    k++;
+    const uint32_t lp = p - base;
+    const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)lp);
+    const uint32_t bt8 = ph >= 4u ? cb8 : lb8;
+    ph = ph == 5u ? 0u : ph + 1u;
+    if (b0 == 0xFFu) {  // "unchanged" block: a single byte
+      p += 1u;
+      continue;
+    }
+    const uint32_t need = 63u - bt8;
+    const uint32_t iq = lp + bt8;  // last non-token byte of the block, 0..126 (bt8 <= 15)
+    const uint32_t Wq = iq < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)Wc, (int)iq)
+                                 : (uint32_t)__builtin_amdgcn_readlane((int)Wn, (int)(iq - 64u));
+    const uint32_t target = Wq + need;
+    const unsigned long long mc = __ballot(Wc >= target);
+    uint32_t e;
+    if (mc) {
+      e = (uint32_t)__builtin_ctzll(mc);
+    } else {
+      const unsigned long long mn = __ballot(Wn >= target);
+      e = 64u + (uint32_t)__builtin_ctzll(mn);  // W grows by >= 1 per byte, so mn != 0
+    }
+    p = base + e + 1u;
+  }
+  if (k & 63u) {  // the last, partial group of records
+    const uint32_t idx = (k & ~63u) + (uint32_t)lane;
+    if (idx < k && idx < cap) out[idx] = (uint16_t)acc;
+  }
+  return k;
+}
+
 // Whole packet by one wave: the simple (serial) index, kept as the A/B baseline of the parallel one.
 __global__ __launch_bounds__(64) void k_index_walk(const FrameDev* __restrict__ frames,
                                                     const uint8_t* __restrict__ stream,

@@ -58,6 +58,7 @@ struct SpecChunkDev {
   uint32_t c;      // chunk number within the packet
 };
 constexpr int kSpecFallbackRows = 64;
+constexpr int kSpecRepairGrid = 4096;   // waves of k_spec_repair (they loop over the list of chunks to walk again)
 constexpr int kSpecPauseLaunches = 64;  // launches a plan goes without speculation after two in which every packet was refused
 #ifndef MIRTJ_SPEC_VER_THREADS
 #define MIRTJ_SPEC_VER_THREADS 1024
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
                                                    const SpecChunkDev* __restrict__ chunks, uint32_t total,
                                                    const uint8_t* __restrict__ stream,
                                                    const QTab* __restrict__ lut, uint16_t* __restrict__ records,
-                                                   uint32_t* __restrict__ nrec, const uint32_t* __restrict__ state) {
+                                                   uint32_t* __restrict__ nrec, uint32_t* __restrict__ wstart,
+                                                   const uint32_t* __restrict__ state) {
   if (state && state[1]) return;  // paused (k_spec_policy)
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[64 * kSpecRingRow];
   const int lane = threadIdx.x;
@@ -199,7 +201,10 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
     }
   }
   flush(1);  // the last, partial group (the slots past cnt are never read)
-  if (act) nrec[g] = cnt;  // > kSpecCap: the span held more blocks than a walker records
+  if (act) {
+    nrec[g] = cnt;  // > kSpecCap: the span held more blocks than a walker records
+    wstart[g] = start;
+  }
 }
 
 // first index in [0, n) whose record is >= v (records ascend), n if none
@@ -222,11 +227,14 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
                                                       const uint16_t* __restrict__ records,
                                                       const uint32_t* __restrict__ nrec, uint32_t* __restrict__ blkoff,
                                                       uint32_t* __restrict__ ok, uint32_t* __restrict__ todo,
-                                                      uint32_t* __restrict__ ntodo, const uint32_t* __restrict__ state) {
+                                                      uint32_t* __restrict__ ntodo, const uint32_t* __restrict__ state,
+                                                      const uint32_t* __restrict__ wstart, uint2* __restrict__ fix,
+                                                      uint32_t* __restrict__ nfix, int pass) {
   if (state && state[1]) {  // paused (k_spec_policy): nothing was walked, nothing is proven
     if (threadIdx.x == 0) ok[blockIdx.x] = 0;
     return;
   }
+  if (pass == 2 && ok[blockIdx.x] != 2u) return;  // the second pass only looks at packets with repaired chunks
   __shared__ uint32_t s_wave[kSpecVerThreads / 64], s_carry[3];  // carry: [1] blocks so far, [2] bad
   __shared__ uint32_t s_i0[kSpecVerThreads], s_base[kSpecVerThreads], s_cnt[kSpecVerThreads];
   const FrameDev f = frames[blockIdx.x];
@@ -245,15 +253,16 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
   __syncthreads();
   for (uint32_t c0 = 0; c0 < nsc; c0 += kSpecVerThreads) {
     const uint32_t c = c0 + (uint32_t)tid;
-    uint32_t cnt = 0, i0 = 0, bad = 0;
+    uint32_t cnt = 0, i0 = 0, bad = 0, soft = 0;
     if (c < nsc) {
       // where chunk c takes over: the last unit-aligned record of its walker before the chunk (record 0,
       // the walker's arbitrary first byte, if it saw no other: the match below then fails)
       auto take_over = [&](uint32_t cc, uint32_t& start, uint32_t& idx) {
         const uint32_t n = min(nrec[sc0 + cc], (uint32_t)kSpecCap);
         const uint16_t* R = records + (size_t)(sc0 + cc) * kSpecCap;
-        start = cc * (uint32_t)kSpecChunk - (uint32_t)kSpecLead;
-        idx = (spec_lower_bound(R, n, (uint32_t)kSpecLead) - 1u) / unit * unit;
+        start = wstart[sc0 + cc];
+        const uint32_t lb = spec_lower_bound(R, n, cc * (uint32_t)kSpecChunk - start);  // >= 1: record 0 is 0
+        idx = (max(lb, 1u) - 1u) / unit * unit;
         return start + R[idx];
       };
       const uint32_t full = nrec[sc0 + c], n = min(full, (uint32_t)kSpecCap);
@@ -267,7 +276,18 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
         uint32_t sn, in;
         const uint32_t h = take_over(c + 1, sn, in);  // absolute position of the hand-over to chunk c + 1
         i1 = spec_lower_bound(R, n, h - start);
-        if (i1 >= n || start + R[i1] != h || i1 % unit != 0u) bad = 1;  // not a (macro)block start of mine
+        if (i1 >= n || start + R[i1] != h || i1 % unit != 0u) {  // not a (macro)block start of mine
+          if (pass == 1 && !bad) {
+            // the next walker had not fallen into step yet: it is re-walked (k_spec_repair) from the last
+            // (macro)block start this one saw, and the packet gets a second pass
+            soft = 1;
+            const uint32_t lb = spec_lower_bound(R, n, (c + 1u) * (uint32_t)kSpecChunk - start);  // records before the next chunk
+            fix[atomicAdd(nfix, 1u)] = make_uint2(sc0 + c + 1u, start + R[(max(lb, 1u) - 1u) / unit * unit]);
+          } else {
+            bad = 1;
+          }
+          i1 = n;
+        }
       }
       if (bad || i1 < i0) bad = 1;
       else cnt = i1 - i0;
@@ -275,7 +295,7 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
     // blocks before this chunk: scan over the tile + carry
     const uint32_t incl = wave_incl_scan(cnt);
     if (lane == 63) s_wave[wv] = incl;
-    const uint32_t anybad = __any(bad) ? 1u : 0u;
+    const uint32_t anybad = (__any(bad) ? 1u : 0u) | (__any(soft) ? 2u : 0u);
     __syncthreads();
     uint32_t before = s_carry[1] + incl - cnt;
     for (int k = 0; k < wv; k++) before += s_wave[k];
@@ -283,7 +303,7 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
     s_base[tid] = before;
     s_cnt[tid] = cnt;
     __syncthreads();
-    if (lane == 0 && anybad) atomicOr(&s_carry[2], 1u);
+    if (lane == 0 && anybad) atomicOr(&s_carry[2], anybad);
     if (tid == kSpecVerThreads - 1) s_carry[1] = before + cnt;
     // recorded starts -> block offsets, one wave per chunk of the tile (harmless if the packet fails later:
     // counts of refused chunks are 0, everything is clipped to the packet's own index, and the exact
@@ -293,7 +313,7 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
       const uint32_t cj = c0 + j, base = s_base[j];
       if (base > last) break;  // bases ascend
       const uint32_t m = min(s_cnt[j], last + 1u - base);
-      const uint32_t start = cj ? cj * (uint32_t)kSpecChunk - (uint32_t)kSpecLead : 0u;
+      const uint32_t start = wstart[sc0 + cj];
       const uint16_t* R = records + (size_t)(sc0 + cj) * kSpecCap + s_i0[j];
       // a chunk holds ~200 blocks: four loads in flight per lane, so that a chunk costs one round trip
       for (uint32_t k0 = 0; k0 < m; k0 += 256) {
@@ -314,16 +334,43 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
   }
   // every block start and the end position must be there: indices 0 .. 6 * nmb
   if (tid == 0) {
-    const uint32_t good = (!s_carry[2] && s_carry[1] >= last + 1u) ? 1u : 0u;
-    ok[blockIdx.x] = good;
-    if (!good) todo[atomicAdd(ntodo, 1u)] = blockIdx.x;
+    // 1 proven, 2 some walkers are being repaired (first pass only), 0 refused
+    uint32_t v = (s_carry[2] & 1u) ? 0u : (s_carry[2] & 2u) ? 2u : s_carry[1] >= last + 1u ? 1u : 0u;
+    ok[blockIdx.x] = v;
+    if (!v) todo[atomicAdd(ntodo, 1u)] = blockIdx.x;
   }
 }
 
+// A walker that had not fallen into step by the end of its lead is walked again, this time from a byte
+// that is known to start a (macro)block if its predecessor is right (the second k_spec_verify pass checks
+// exactly that): one WAVE per such chunk, the block-by-block walker of rtj_decode_kernels.h (a lane-serial
+// walker would take as long for one chunk as k_spec_walk takes for all).  grid: any; loops over the list.
+__global__ __launch_bounds__(64) void k_spec_repair(const FrameDev* __restrict__ frames,
+                                                     const SpecChunkDev* __restrict__ chunks,
+                                                     const uint8_t* __restrict__ stream,
+                                                     const QTab* __restrict__ lut, uint16_t* __restrict__ records,
+                                                     uint32_t* __restrict__ nrec, uint32_t* __restrict__ wstart,
+                                                     const uint2* __restrict__ fix, const uint32_t* __restrict__ nfix) {
+  const uint32_t n = *nfix;
+  for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const uint2 e = fix[i];
+    const SpecChunkDev sc = chunks[e.x];
+    const FrameDev f = frames[sc.frame];
+    const uint32_t limit = (sc.c + 1u) * (uint32_t)kSpecChunk;  // where the walker's span ends
+    const uint32_t cnt = walk_record(f, stream, lut, e.y, limit, records + (size_t)e.x * kSpecCap, (uint32_t)kSpecCap);
+    if (threadIdx.x == 0) {
+      nrec[e.x] = cnt;
+      wstart[e.x] = e.y;
+    }
+  }
+}
+
+
 // After k_spec_verify, one workgroup.  todo_cnt[0] = packets refused in this launch, todo_cnt[1..] = the list;
-// state[0] = launches in a row that refused everything, state[1] = launches left without speculation.
+// state[0] = launches in a row that were lost (see below), state[1] = launches left without speculation.
 // While paused k_spec_walk and k_spec_verify return at once and this kernel puts every packet on the list.
-__global__ __launch_bounds__(256) void k_spec_policy(uint32_t n, uint32_t* __restrict__ todo_cnt, uint32_t* __restrict__ state) {
+__global__ __launch_bounds__(256) void k_spec_policy(uint32_t n, uint32_t walkers, uint32_t* __restrict__ todo_cnt,
+                                                      const uint32_t* __restrict__ nfix, uint32_t* __restrict__ state) {
   const uint32_t pause = state[1];
   if (pause) {
     for (uint32_t i = threadIdx.x; i < n; i += 256) todo_cnt[1 + i] = i;
@@ -331,10 +378,13 @@ __global__ __launch_bounds__(256) void k_spec_policy(uint32_t n, uint32_t* __res
     if (threadIdx.x == 0) {
       todo_cnt[0] = n;
       state[1] = pause - 1u;
-      if (pause == 1u) state[0] = 1u;  // one more launch that refuses everything pauses again
+      if (pause == 1u) state[0] = 1u;  // one more lost launch pauses again
     }
   } else if (threadIdx.x == 0) {
-    const uint32_t streak = todo_cnt[0] == n ? state[0] + 1u : 0u;
+    // a lost launch: every packet refused, or so many walkers repaired (one wave each) that the exact
+    // kernels would have been quicker
+    const bool lost = todo_cnt[0] == n || 4u * *nfix > walkers;
+    const uint32_t streak = lost ? state[0] + 1u : 0u;
     state[0] = streak;
     if (streak >= 2u) state[1] = (uint32_t)kSpecPauseLaunches;
   }
