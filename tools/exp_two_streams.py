@@ -5,7 +5,7 @@ import importlib, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 P = importlib.import_module("gmerlin-avdecoder_amd")
-w, h, Q, n = 1920, 1088, 255, 256
+w, h, Q, n = 1920, 1088, 255, int(os.environ.get("N", "1024"))
 fsz = w * h * 3 // 2
 
 def setup(dev, first, cnt):
