@@ -221,7 +221,8 @@ def main():
                                 "ms_per_launch": dec["ms"], "alg_bytes_per_launch": alg_bytes},
             "kernels": kernels,
             "index_mode": os.environ.get("MI_RTJ_INDEX", "parallel"),
-            "speculative_index": dict(zip(("packets_proven", "stream_chunks"), plan.spec_stats())),
+            "speculative_index": dict(zip(("packets_proven", "stream_chunks"), plan.spec_stats()),
+                                      chunks_repaired=getattr(plan, "repaired", 0)),
             "path_gbs": round(alg_bytes * a.steps / dt / 1e9, 2),
         }
         if world == 1 and not a.no_cpu:

@@ -67,7 +67,7 @@ def load():
     L.mi_rtj_plan_info.argtypes = [vp, C.POINTER(C.c_int), u64p, u64p, u64p]
     L.mi_rtj_plan_profile.argtypes = [vp, C.c_int]
     L.mi_rtj_plan_times.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
-    L.mi_rtj_plan_spec_stats.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
+    L.mi_rtj_plan_spec_stats.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.mi_rtj_plan_read_index.argtypes = [vp, u32p, C.c_size_t]
     L.mi_rtj_synth_frames.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, vp]
     L.mi_rtj_encode_bound.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
@@ -125,8 +125,9 @@ class Plan:
 
     def spec_stats(self):
         """(packets proven by the speculative index in the last decode, stream chunks it covered; 0 = unused)."""
-        pr, wk = C.c_int(), C.c_longlong()
-        self.owner._chk(self.owner.L.mi_rtj_plan_spec_stats(self.h, C.byref(pr), C.byref(wk)))
+        pr, wk, rp = C.c_int(), C.c_longlong(), C.c_longlong()
+        self.owner._chk(self.owner.L.mi_rtj_plan_spec_stats(self.h, C.byref(pr), C.byref(wk), C.byref(rp)))
+        self.repaired = rp.value
         return pr.value, wk.value
 
     def times(self):

@@ -618,16 +618,20 @@ int mi_rtj_plan_times(mi_rtj_plan* p, float ms[MI_RTJ_NUM_KERNELS], int* launche
   return MI_RTJ_OK;
 }
 
-int mi_rtj_plan_spec_stats(mi_rtj_plan* p, int* proven, long long* walkers) {
-  if (!p || !proven || !walkers) return MI_RTJ_ERR_ARG;
+int mi_rtj_plan_spec_stats(mi_rtj_plan* p, int* proven, long long* walkers, long long* repaired) {
+  if (!p || !proven || !walkers || !repaired) return MI_RTJ_ERR_ARG;
   mi_rtj_ctx* c = p->ctx;
   *proven = 0;
+  *repaired = 0;
   *walkers = p->spec ? (long long)p->n_spec : 0;
   if (!p->spec) return MI_RTJ_OK;
   std::vector<uint32_t> ok(p->n);
   HIPCHK(c, hipSetDevice(c->device));
+  uint32_t nfix = 0;
   HIPCHK(c, hipMemcpyAsync(ok.data(), p->d_spec_ok, sizeof(uint32_t) * p->n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&nfix, p->d_spec_nfix, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  *repaired = nfix;
   for (uint32_t v : ok) *proven += v == 1u ? 1 : 0;
   return MI_RTJ_OK;
 }

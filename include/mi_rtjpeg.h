@@ -110,8 +110,9 @@ void mi_rtj_plan_profile(mi_rtj_plan *plan, int enable);
 int mi_rtj_plan_times(mi_rtj_plan *plan, float ms[MI_RTJ_NUM_KERNELS], int *launches);
 /* After a decode: *walkers = stream chunks the speculative index covered (0: it was not used for this
  * plan — small batch, MI_RTJ_SPEC=0, or an A/B index mode), *proven = packets whose index its proof step
- * accepted; the others were indexed by the exact kernels.  Synchronises the instance's stream. */
-int mi_rtj_plan_spec_stats(mi_rtj_plan *plan, int *proven, long long *walkers);
+ * accepted (the others were indexed by the exact kernels), *repaired = chunks that were walked a second
+ * time before that.  Synchronises the instance's stream. */
+int mi_rtj_plan_spec_stats(mi_rtj_plan *plan, int *proven, long long *walkers, long long *repaired);
 /* Test hook: copy the plan's block-start index (relative to each packet's first data byte,
  * nblocks+1 entries per frame, frames back to back) to the host after a decode. */
 int mi_rtj_plan_read_index(mi_rtj_plan *plan, uint32_t *dst, size_t max_entries);
