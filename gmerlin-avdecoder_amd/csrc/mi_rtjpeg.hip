@@ -31,6 +31,7 @@ std::string g_create_err = "";
 
 struct Timed {
   hipEvent_t a = nullptr, b = nullptr;
+  bool owns_a = true;  // false: `a` is the previous kernel's `b` (kernels run back to back on one stream)
 };
 
 }  // namespace
@@ -265,17 +266,26 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
   mi_rtj_ctx* c = p->ctx;
   const uint8_t* st = (const uint8_t*)d_stream;
   Timed t[MI_RTJ_NUM_KERNELS];
+  // while profiling: one event after every kernel; a kernel's start is its predecessor's end (they run back
+  // to back on one stream), so a launch costs one event record per kernel instead of two
+  hipEvent_t prev = nullptr;
   auto begin = [&](int k) -> int {
     if (!p->profile) return MI_RTJ_OK;
+    if (prev) {
+      t[k].a = prev;
+      t[k].owns_a = false;
+      return MI_RTJ_OK;
+    }
     HIPCHK(c, hipEventCreate(&t[k].a));
-    HIPCHK(c, hipEventCreate(&t[k].b));
     HIPCHK(c, hipEventRecord(t[k].a, c->stream));
     return MI_RTJ_OK;
   };
   auto end = [&](int k) -> int {
     if (!p->profile) return MI_RTJ_OK;
+    HIPCHK(c, hipEventCreate(&t[k].b));
     HIPCHK(c, hipEventRecord(t[k].b, c->stream));
     p->ev[k].push_back(t[k]);
+    prev = t[k].b;
     return MI_RTJ_OK;
   };
   int rc;
@@ -355,7 +365,7 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
 
 void drop_events(std::vector<Timed>& v) {
   for (auto& t : v) {
-    if (t.a) (void)hipEventDestroy(t.a);
+    if (t.a && t.owns_a) (void)hipEventDestroy(t.a);
     if (t.b) (void)hipEventDestroy(t.b);
   }
   v.clear();
