@@ -210,7 +210,7 @@ int plan_alloc_chunks(mi_rtj_plan* p) {
       p->h_spec_base.push_back((uint32_t)p->h_spec_chunks.size());
     }
     p->n_spec = p->h_spec_chunks.size();
-    if ((p->n_spec + 1) * (uint64_t)kSpecCap * 2 >= 0xFFFFFFFFull) p->spec = false;  // record offsets are 32-bit
+    if (p->n_spec >= 0x7FFFFFFFull) p->spec = false;  // walker numbers are 32-bit
   }
   if (p->spec) {
     if (p->n_spec > p->cap_spec) {

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
   // ring per lane in LDS and leave for HBM eight at a time (one 16-byte store): a 2-byte global store
   // per block end was 40 % of the kernel.  Idle lanes of the last wave own the spare row after the last
   // walker's.
-  const uint32_t row0 = 2u * (act ? g : total) * (uint32_t)kSpecCap;
+  const size_t row0 = 2u * (size_t)(act ? g : total) * (size_t)kSpecCap;
   uint8_t* const rec8 = (uint8_t*)records;
   uint8_t* const ring = s_ring + lane * kSpecRingRow;
   const uint32_t ring_a = lds_address(ring);
