@@ -308,8 +308,12 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
       HIPCHK(c, hipMemsetAsync(p->d_spec_todo, 0, sizeof(uint32_t), c->stream));
       HIPCHK(c, hipMemsetAsync(p->d_spec_nfix, 0, sizeof(uint32_t), c->stream));
       if ((rc = begin(MI_RTJ_K_SPEC_WALK)) != MI_RTJ_OK) return rc;
-      hipLaunchKernelGGL(k_spec_walk, dim3((unsigned)((p->n_spec + 63) / 64)), dim3(64), 0, c->stream, p->d_frames,
-                         p->d_spec_chunks, (uint32_t)p->n_spec, st, c->d_lut, p->d_spec_rec, p->d_spec_nrec, p->d_spec_wstart, state);
+      if (p->one_block_type)
+        hipLaunchKernelGGL(k_spec_walk<false>, dim3((unsigned)((p->n_spec + 63) / 64)), dim3(64), 0, c->stream, p->d_frames,
+                           p->d_spec_chunks, (uint32_t)p->n_spec, st, c->d_lut, p->d_spec_rec, p->d_spec_nrec, p->d_spec_wstart, state);
+      else
+        hipLaunchKernelGGL(k_spec_walk<true>, dim3((unsigned)((p->n_spec + 63) / 64)), dim3(64), 0, c->stream, p->d_frames,
+                           p->d_spec_chunks, (uint32_t)p->n_spec, st, c->d_lut, p->d_spec_rec, p->d_spec_nrec, p->d_spec_wstart, state);
       if ((rc = end(MI_RTJ_K_SPEC_WALK)) != MI_RTJ_OK) return rc;
       if ((rc = begin(MI_RTJ_K_SPEC_VERIFY)) != MI_RTJ_OK) return rc;
       // first pass; walkers that had not fallen into step are walked again from a known block start; second

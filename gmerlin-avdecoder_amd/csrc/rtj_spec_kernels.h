@@ -98,6 +98,30 @@ constexpr int kSpecVerThreads = MIRTJ_SPEC_VER_THREADS;  // k_spec_verify: chunk
       : [w] "v"(w_), [k63] "v"(k63), [kn64] "v"(kn64), [ring] "v"(ring_a), [val] "v"(val_), [lb] "v"(lb), [cb] "v"(cb) \
       : "vcc", "memory")
 
+// The same when every packet of the launch has lb8 == cb8 (two thirds of the qualities): all blocks parse
+// alike, no phase to track, 12 vector instructions.
+#define MIRTJ_SPEC_STEP1(SEL)                                                                                     \
+  asm("v_sub_u32_sdwa %[t], sext(%[w]), %[k63] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SEL               \
+      " src1_sel:DWORD\n\t"                                                                                       \
+      "v_cmp_eq_i32_e32 vcc, %[kn64], %[t]\n\t"                                                                    \
+      "v_cmp_lt_i32_e64 %[ma], %[u], %[rb]\n\t"                                                                    \
+      "v_max_i32_e32 %[wt], 1, %[t]\n\t"                                                                           \
+      "s_and_b64 vcc, vcc, %[em]\n\t"                                                                              \
+      "v_bfe_u32 %[idx], %[cnt], 0, 5\n\t"                                                                         \
+      "v_cndmask_b32_e64 %[wr], 1, 64, vcc\n\t"                                                                    \
+      "v_cndmask_b32_e64 %[wt], %[wt], %[wr], %[ma]\n\t"                                                           \
+      "v_add_u32_e32 %[u], %[u], %[wt]\n\t"                                                                        \
+      "v_cmp_lt_i32_e64 %[em], 63, %[u]\n\t"                                                                       \
+      "v_lshl_add_u32 %[ra], %[idx], 1, %[ring]\n\t"                                                               \
+      "ds_write_b16 %[ra], %[val]\n\t"                                                                             \
+      "v_addc_co_u32_e64 %[cnt], vcc, 0, %[cnt], %[em]\n\t"                                                        \
+      "v_cndmask_b32_e64 %[u], %[u], 0, %[em]"                                                                     \
+      : [u] "+v"(u), [cnt] "+v"(cnt), [em] "+s"(em), [t] "=&v"(t_), [wt] "=&v"(wt_), [wr] "=&v"(wr_),              \
+        [idx] "=&v"(idx_), [ra] "=&v"(ra_), [ma] "=&s"(ma_)                                                        \
+      : [w] "v"(w_), [k63] "v"(k63), [kn64] "v"(kn64), [ring] "v"(ring_a), [val] "v"(val_), [rb] "v"(rb)           \
+      : "vcc", "memory")
+
+template <bool PHASE>
 __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ frames,
                                                    const SpecChunkDev* __restrict__ chunks, uint32_t total,
                                                    const uint8_t* __restrict__ stream,
@@ -190,11 +214,20 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
         int t_, wt_, wr_;
         uint32_t idx_, ra_;
         uint64_t ma_, mx_, my_;
-        switch (b & 3) {
-          case 0: MIRTJ_SPEC_STEP("BYTE_0"); break;
-          case 1: MIRTJ_SPEC_STEP("BYTE_1"); break;
-          case 2: MIRTJ_SPEC_STEP("BYTE_2"); break;
-          default: MIRTJ_SPEC_STEP("BYTE_3"); break;
+        if (PHASE) {
+          switch (b & 3) {
+            case 0: MIRTJ_SPEC_STEP("BYTE_0"); break;
+            case 1: MIRTJ_SPEC_STEP("BYTE_1"); break;
+            case 2: MIRTJ_SPEC_STEP("BYTE_2"); break;
+            default: MIRTJ_SPEC_STEP("BYTE_3"); break;
+          }
+        } else {
+          switch (b & 3) {
+            case 0: MIRTJ_SPEC_STEP1("BYTE_0"); break;
+            case 1: MIRTJ_SPEC_STEP1("BYTE_1"); break;
+            case 2: MIRTJ_SPEC_STEP1("BYTE_2"); break;
+            default: MIRTJ_SPEC_STEP1("BYTE_3"); break;
+          }
         }
       }
       flush(8);  // at most 7 + 16 records are staged at this point
