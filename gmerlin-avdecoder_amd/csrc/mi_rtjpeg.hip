@@ -931,8 +931,8 @@ int mi_rtj_copy_ceiling(mi_rtj_ctx* c, const void* d_src, void* d_dst, size_t by
   HIPCHK(c, hipEventSynchronize(e1));
   float ms = 0;
   HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
   *gbs = 2.0 * (double)bytes * reps / ((double)ms * 1e6);
   return MI_RTJ_OK;
 }

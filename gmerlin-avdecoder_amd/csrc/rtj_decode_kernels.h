@@ -505,11 +505,11 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
           const uint32_t w = wd[t >> 2];
           const bool is_raw = first && (B8 >= 0 ? t <= B8 : t <= (int)bt8);
           if (is_raw) {
-            e[k] = *(const lds_u32_t*)(tab_a + 4u * (uint32_t)t);
+            e[k] = *(const lds_u32_t*)(uintptr_t)(tab_a + 4u * (uint32_t)t);
             svb[k] = 0;
           } else {
             svb[k] = sbyte_minus(w, t & 3, k63);  // token - 63: > 0 for a run, its length
-            e[k] = *(const lds_u32_t*)(uint32_t)ca;
+            e[k] = *(const lds_u32_t*)(uintptr_t)(uint32_t)ca;
             ca = med3_i32(ca + 4, (svb[k] << 2) + ca, ca_end);  // == min(ca + 4 * max(1, svb), end) below the end
           }
         }
@@ -519,11 +519,11 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
           const uint32_t w = wd[t >> 2];
           const bool is_raw = first && (B8 >= 0 ? t <= B8 : t <= (int)bt8);
           if (is_raw) {
-            *(lds_i16_t*)(my_a + (uint32_t)slot_byte(t)) = (int16_t)mul_byte_hi16(w, e[k], t & 3, t != 0);
+            *(lds_i16_t*)(uintptr_t)(my_a + (uint32_t)slot_byte(t)) = (int16_t)mul_byte_hi16(w, e[k], t & 3, t != 0);
           } else {
             int prod = mul_byte_hi16(w, e[k], t & 3, true);  // |byte| < 2^8, dequantiser < 2^14; stored as int16
             prod = svb[k] > 0 ? 0 : prod;
-            *(lds_i16_t*)(my_a + (e[k] & 0xFFFFu)) = (int16_t)prod;
+            *(lds_i16_t*)(uintptr_t)(my_a + (e[k] & 0xFFFFu)) = (int16_t)prod;
           }
         }
         ca = min(ca, ca_end);

@@ -174,7 +174,6 @@ __device__ __forceinline__ void summarize_chunk(const FrameDev* __restrict__ fra
   if (c >= f.nchunks) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const uint32_t cbase = c * (uint32_t)kChunk;
-  const uint8_t* s_b = (const uint8_t*)s_b4;
 
   // ---- 1. stage kStageN bytes starting at cbase; bytes at or past data_len read as 0 ----
   {
