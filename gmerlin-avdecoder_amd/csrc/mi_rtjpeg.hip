@@ -82,6 +82,7 @@ struct mi_rtj_plan {
   uint16_t* d_spec_rec = nullptr;          // [walkers][kSpecCap]
   uint32_t* d_spec_nrec = nullptr;
   uint32_t* d_spec_wstart = nullptr;       // [walkers]: first byte each walker parsed (repairs move it)
+  uint2* d_spec_hand = nullptr;            // [walkers]: where a chunk takes over / where the next one has to
   uint2* d_spec_fix = nullptr;             // [walkers]: (walker, byte to start from) of the chunks to walk again
   uint32_t* d_spec_nfix = nullptr;
   uint32_t* d_spec_ok = nullptr;           // [n]: 1 = the packet's index is proven
@@ -220,6 +221,7 @@ int plan_alloc_chunks(mi_rtj_plan* p) {
         (void)hipFree(p->d_spec_rec);
         (void)hipFree(p->d_spec_nrec);
         (void)hipFree(p->d_spec_wstart);
+        (void)hipFree(p->d_spec_hand);
         (void)hipFree(p->d_spec_fix);
         p->d_spec_chunks = nullptr;
       }
@@ -227,6 +229,7 @@ int plan_alloc_chunks(mi_rtj_plan* p) {
       HIPCHK(c, hipMalloc((void**)&p->d_spec_rec, sizeof(uint16_t) * kSpecCap * (p->n_spec + 1)));  // + a spare row for idle lanes
       HIPCHK(c, hipMalloc((void**)&p->d_spec_nrec, sizeof(uint32_t) * p->n_spec));
       HIPCHK(c, hipMalloc((void**)&p->d_spec_wstart, sizeof(uint32_t) * p->n_spec));
+      HIPCHK(c, hipMalloc((void**)&p->d_spec_hand, sizeof(uint2) * p->n_spec));
       HIPCHK(c, hipMalloc((void**)&p->d_spec_fix, sizeof(uint2) * p->n_spec));
       if (!p->d_spec_nfix) HIPCHK(c, hipMalloc((void**)&p->d_spec_nfix, sizeof(uint32_t)));
       p->cap_spec = p->n_spec;
@@ -310,22 +313,22 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
       if ((rc = begin(MI_RTJ_K_SPEC_WALK)) != MI_RTJ_OK) return rc;
       if (p->one_block_type)
         hipLaunchKernelGGL(k_spec_walk<false>, dim3((unsigned)((p->n_spec + 63) / 64)), dim3(64), 0, c->stream, p->d_frames,
-                           p->d_spec_chunks, (uint32_t)p->n_spec, st, c->d_lut, p->d_spec_rec, p->d_spec_nrec, p->d_spec_wstart, state);
+                           p->d_spec_chunks, (uint32_t)p->n_spec, st, c->d_lut, p->d_spec_rec, p->d_spec_nrec, p->d_spec_wstart, p->d_spec_hand, state);
       else
         hipLaunchKernelGGL(k_spec_walk<true>, dim3((unsigned)((p->n_spec + 63) / 64)), dim3(64), 0, c->stream, p->d_frames,
-                           p->d_spec_chunks, (uint32_t)p->n_spec, st, c->d_lut, p->d_spec_rec, p->d_spec_nrec, p->d_spec_wstart, state);
+                           p->d_spec_chunks, (uint32_t)p->n_spec, st, c->d_lut, p->d_spec_rec, p->d_spec_nrec, p->d_spec_wstart, p->d_spec_hand, state);
       if ((rc = end(MI_RTJ_K_SPEC_WALK)) != MI_RTJ_OK) return rc;
       if ((rc = begin(MI_RTJ_K_SPEC_VERIFY)) != MI_RTJ_OK) return rc;
       // first pass; walkers that had not fallen into step are walked again from a known block start; second
       // pass over the packets concerned (both return at once when there is nothing to repair)
       hipLaunchKernelGGL(k_spec_verify, dim3(p->n), dim3(kSpecVerThreads), 0, c->stream, p->d_frames, p->d_spec_base, c->d_lut,
                          p->d_spec_rec, p->d_spec_nrec, p->d_blkoff, p->d_spec_ok, p->d_spec_todo + 1, p->d_spec_todo, state,
-                         p->d_spec_wstart, p->d_spec_fix, p->d_spec_nfix, 1);
+                         p->d_spec_wstart, p->d_spec_hand, p->d_spec_fix, p->d_spec_nfix, 1);
       hipLaunchKernelGGL(k_spec_repair, dim3(kSpecRepairGrid), dim3(64), 0, c->stream, p->d_frames, p->d_spec_chunks, st,
-                         c->d_lut, p->d_spec_rec, p->d_spec_nrec, p->d_spec_wstart, p->d_spec_fix, p->d_spec_nfix);
+                         c->d_lut, p->d_spec_rec, p->d_spec_nrec, p->d_spec_wstart, p->d_spec_hand, p->d_spec_fix, p->d_spec_nfix);
       hipLaunchKernelGGL(k_spec_verify, dim3(p->n), dim3(kSpecVerThreads), 0, c->stream, p->d_frames, p->d_spec_base, c->d_lut,
                          p->d_spec_rec, p->d_spec_nrec, p->d_blkoff, p->d_spec_ok, p->d_spec_todo + 1, p->d_spec_todo, state,
-                         p->d_spec_wstart, p->d_spec_fix, p->d_spec_nfix, 2);
+                         p->d_spec_wstart, p->d_spec_hand, p->d_spec_fix, p->d_spec_nfix, 2);
       if ((rc = end(MI_RTJ_K_SPEC_VERIFY)) != MI_RTJ_OK) return rc;
       if (state) hipLaunchKernelGGL(k_spec_policy, dim3(1), dim3(256), 0, c->stream, (uint32_t)p->n, (uint32_t)p->n_spec, p->d_spec_todo, p->d_spec_nfix, state);
     }
@@ -586,6 +589,7 @@ void mi_rtj_plan_destroy(mi_rtj_plan* p) {
   if (p->d_spec_rec) (void)hipFree(p->d_spec_rec);
   if (p->d_spec_nrec) (void)hipFree(p->d_spec_nrec);
   if (p->d_spec_wstart) (void)hipFree(p->d_spec_wstart);
+  if (p->d_spec_hand) (void)hipFree(p->d_spec_hand);
   if (p->d_spec_fix) (void)hipFree(p->d_spec_fix);
   if (p->d_spec_nfix) (void)hipFree(p->d_spec_nfix);
   if (p->d_spec_todo) (void)hipFree(p->d_spec_todo);

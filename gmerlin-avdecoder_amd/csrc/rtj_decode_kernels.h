@@ -128,9 +128,12 @@ __device__ __forceinline__ void walk_blocks(const FrameDev& f, const uint8_t* __
 // (rtj_spec_kernels.h): from byte p_start, taken to start a macroblock, every block start below `limit` is
 // recorded as a 16-bit offset from p_start (the first record is 0).  Returns the number of blocks seen;
 // only the first `cap` are stored.
+// take / tail: (index << 16 | offset) of the last unit-aligned record below `mid` / below `limit`, the unit being
+// the macroblock, or the block when lb8 == cb8.
 __device__ __forceinline__ uint32_t walk_record(const FrameDev& f, const uint8_t* __restrict__ stream,
-                                                const QTab* __restrict__ lut, uint32_t p_start, uint32_t limit,
-                                                uint16_t* __restrict__ out, uint32_t cap) {
+                                                const QTab* __restrict__ lut, uint32_t p_start, uint32_t mid,
+                                                uint32_t limit, uint16_t* __restrict__ out, uint32_t cap,
+                                                uint32_t& take, uint32_t& tail) {
   const int lane = threadIdx.x & 63;
   const uint8_t* g = stream + f.data_off;
   const uint32_t len = f.data_len;
@@ -145,7 +148,14 @@ __device__ __forceinline__ uint32_t walk_record(const FrameDev& f, const uint8_t
   uint32_t Wc = wave_incl_scan(token_weight(cur));
   uint32_t Wn = wave_incl_scan(token_weight(nxt)) + (uint32_t)__builtin_amdgcn_readlane((int)Wc, 63);
   uint32_t p = p_start, ph = 0, acc = 0, k = 0;
+  const bool by_block = lb8 == cb8;
+  take = tail = 0;
   while (p < limit) {
+    if (by_block || ph == 0u) {  // a unit-aligned record
+      const uint32_t v = (k << 16) | (p - p_start);
+      if (p < mid) take = v;
+      tail = v;
+    }
     while (p - base >= 64u) {  // slide the two windows forward
       base += 64u;
       cur = nxt;

@@ -14,8 +14,8 @@
 //                  64 chunks advance in lockstep per wave: ~20 vector instructions per byte for 64
 //                  streams, against ~20 per BLOCK POSITION AND TYPE in k_index_summarize.
 //   k_spec_verify  per packet: the last (macro)block start a walker saw in its lead, i.e. before its
-//                  chunk, must also be a (macro)block start of its predecessor, whose own span ends
-//                  there; chunk 0 starts at byte 0.  Two walkers that stand on the same byte in the same
+//                  chunk, must be the last one its predecessor saw before the end of its span, which is
+//                  the same byte (the walkers report both); chunk 0 starts at byte 0.  Two walkers that stand on the same byte in the same
 //                  phase go on alike, so by induction every walker is on the true chain from that
 //                  hand-over point on: the check is exact, not a heuristic — it either proves the whole
 //                  packet's index or rejects it.
@@ -51,7 +51,7 @@ constexpr uint64_t kSpecMinWalkers = 40000;  // below this (~100 MB of packets) 
 constexpr int kSpecRingRow = 64 + 16;       // LDS bytes per lane of the record ring: 32 records + bank padding
 constexpr int kSpecRow = kSpecTile + 16;  // LDS bytes per lane: tile + the dword after it + bank padding
 static_assert(kSpecSpan % kSpecTile == 0 && kSpecSpan < 65536, "walker span: whole tiles, 16-bit positions");
-static_assert(kSpecLead >= 6 * 64 + 64, "the lead must hold at least one whole macroblock");
+static_assert(kSpecLead >= 6 * 64 + 64 && kSpecLead % kSpecTile == 0 && kSpecChunk % kSpecTile == 0, "the lead: at least one whole macroblock, whole tiles");
 
 struct SpecChunkDev {
   uint32_t frame;  // index into the plan's frames
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
                                                    const uint8_t* __restrict__ stream,
                                                    const QTab* __restrict__ lut, uint16_t* __restrict__ records,
                                                    uint32_t* __restrict__ nrec, uint32_t* __restrict__ wstart,
-                                                   const uint32_t* __restrict__ state) {
+                                                   uint2* __restrict__ hand, const uint32_t* __restrict__ state) {
   if (state && state[1]) return;  // paused (k_spec_policy)
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[64 * kSpecRingRow];
   const int lane = threadIdx.x;
@@ -193,10 +193,32 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
     }
   };
 
+  // (index << 16 | position) of the last unit-aligned record below `limit` (walker-relative); the unit is the
+  // macroblock, or the block when lb8 == cb8 (k_spec_verify).  Called between bytes: at most the newest
+  // record can sit AT the limit, and the records wanted are among the last seven, i.e. still in the ring.
+  const bool by_block = lb == cb;
+  auto last_aligned_below = [&](uint32_t limit) -> uint32_t {
+    const uint32_t newest = *(const uint16_t*)(ring + (((cnt - 1u) & 31u) << 1));
+    const uint32_t d = newest >= limit ? 1u : 0u, n = cnt - d;
+    // block cnt-1 has phase 5-q, so record n-1 has phase (5-q-d) mod 6: no division (one by a lane-dependent
+    // value, or even by 6, does not get through the compiler next to the SGPR-mask assembly)
+    int r = 5 - (int)q - (int)d;
+    r = r < 0 ? r + 6 : r;
+    const uint32_t idx = n - 1u - (by_block ? 0u : (uint32_t)r);
+    return (idx << 16) | *(const uint16_t*)(ring + ((idx & 31u) << 1));
+  };
+  uint32_t take = 0;  // where this walker's chunk takes over from its predecessor (chunk 0: byte 0, record 0)
+  uint32_t tail0 = 0;
+
   request(0);
   for (int t = 0; t < kSpecSpan / kSpecTile; t++) {
     // the tile is parsed out of registers (fully unrolled: 128 byte steps); staging it in LDS for a
     // smaller loop body capped the kernel at 11 waves per CU
+    if (t == kSpecLead / kSpecTile) {  // the chunk begins with this tile
+      const uint32_t v = last_aligned_below((uint32_t)kSpecLead);
+      take = sc.c ? v : 0u;
+    }
+    if (t == kSpecChunk / kSpecTile) tail0 = last_aligned_below((uint32_t)kSpecChunk);  // chunk 0 (no lead) ends here
     uint32_t cur[33];
 #pragma unroll
     for (int k = 0; k < 33; k++) cur[k] = buf[k];
@@ -237,18 +259,9 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
   if (act) {
     nrec[g] = cnt;  // > kSpecCap: the span held more blocks than a walker records
     wstart[g] = start;
+    const uint32_t tail = last_aligned_below((uint32_t)kSpecSpan);
+    hand[g] = make_uint2(take, sc.c ? tail : tail0);  // .y: what the next chunk must take over from
   }
-}
-
-// first index in [0, n) whose record is >= v (records ascend), n if none
-__device__ __forceinline__ uint32_t spec_lower_bound(const uint16_t* __restrict__ r, uint32_t n, uint32_t v) {
-  uint32_t lo = 0, hi = n;
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (r[mid] < v) lo = mid + 1;
-    else hi = mid;
-  }
-  return lo;
 }
 
 // One workgroup per packet: the chain check, the block numbering, and — the numbering is all it needs —
@@ -261,7 +274,8 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
                                                       const uint32_t* __restrict__ nrec, uint32_t* __restrict__ blkoff,
                                                       uint32_t* __restrict__ ok, uint32_t* __restrict__ todo,
                                                       uint32_t* __restrict__ ntodo, const uint32_t* __restrict__ state,
-                                                      const uint32_t* __restrict__ wstart, uint2* __restrict__ fix,
+                                                      const uint32_t* __restrict__ wstart,
+                                                      const uint2* __restrict__ hand, uint2* __restrict__ fix,
                                                       uint32_t* __restrict__ nfix, int pass) {
   if (state && state[1]) {  // paused (k_spec_policy): nothing was walked, nothing is proven
     if (threadIdx.x == 0) ok[blockIdx.x] = 0;
@@ -276,7 +290,6 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
   // lb8 == cb8: every block parses alike, walkers fall into step with the BLOCK chain but keep whatever
   // macroblock phase they assumed; the unit of the chain check is then the block, and the phase follows
   // from the global block number
-  const uint32_t unit = lut[f.qidx].lb8 == lut[f.qidx].cb8 ? 1u : 6u;
   const uint32_t last = 6u * f.nmb;  // the index holds one entry past the last block: the end position
   uint32_t* const out = blkoff + f.blk_base;
   if (tid == 0) {
@@ -288,41 +301,31 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
     const uint32_t c = c0 + (uint32_t)tid;
     uint32_t cnt = 0, i0 = 0, bad = 0, soft = 0;
     if (c < nsc) {
-      // where chunk c takes over: the last unit-aligned record of its walker before the chunk (record 0,
-      // the walker's arbitrary first byte, if it saw no other: the match below then fails)
-      auto take_over = [&](uint32_t cc, uint32_t& start, uint32_t& idx) {
-        const uint32_t n = min(nrec[sc0 + cc], (uint32_t)kSpecCap);
-        const uint16_t* R = records + (size_t)(sc0 + cc) * kSpecCap;
-        start = wstart[sc0 + cc];
-        const uint32_t lb = spec_lower_bound(R, n, cc * (uint32_t)kSpecChunk - start);  // >= 1: record 0 is 0
-        idx = (max(lb, 1u) - 1u) / unit * unit;
-        return start + R[idx];
-      };
+      // The walkers left, per chunk, the last unit-aligned record before the chunk (hand.x: where it takes
+      // over; record 0, its arbitrary first byte, if it saw no other) and the last one before the end of the
+      // span (hand.y: where the next chunk has to take over), each as index << 16 | position.
       const uint32_t full = nrec[sc0 + c], n = min(full, (uint32_t)kSpecCap);
-      const uint16_t* R = records + (size_t)(sc0 + c) * kSpecCap;
-      uint32_t start = 0;
+      const uint2 mine = hand[sc0 + c];
       bad = full > (uint32_t)kSpecCap;  // the walker ran out of slots
-      if (c) (void)take_over(c, start, i0);
+      i0 = c ? mine.x >> 16 : 0u;
       uint32_t i1 = n;  // the packet's last walker: everything it saw (bytes past the packet read as 0)
       if (c + 1 < nsc) {
         if (nrec[sc0 + c + 1] > (uint32_t)kSpecCap) bad = 1;
-        uint32_t sn, in;
-        const uint32_t h = take_over(c + 1, sn, in);  // absolute position of the hand-over to chunk c + 1
-        i1 = spec_lower_bound(R, n, h - start);
-        if (i1 >= n || start + R[i1] != h || i1 % unit != 0u) {  // not a (macro)block start of mine
+        const uint32_t h = wstart[sc0 + c + 1] + (hand[sc0 + c + 1].x & 0xFFFFu);  // where chunk c + 1 took over
+        const uint32_t t = wstart[sc0 + c] + (mine.y & 0xFFFFu);                    // where it had to
+        i1 = mine.y >> 16;
+        if (h != t) {
           if (pass == 1 && !bad) {
             // the next walker had not fallen into step yet: it is re-walked (k_spec_repair) from the last
             // (macro)block start this one saw, and the packet gets a second pass
             soft = 1;
-            const uint32_t lb = spec_lower_bound(R, n, (c + 1u) * (uint32_t)kSpecChunk - start);  // records before the next chunk
-            fix[atomicAdd(nfix, 1u)] = make_uint2(sc0 + c + 1u, start + R[(max(lb, 1u) - 1u) / unit * unit]);
+            fix[atomicAdd(nfix, 1u)] = make_uint2(sc0 + c + 1u, t);
           } else {
             bad = 1;
           }
-          i1 = n;
         }
       }
-      if (bad || i1 < i0) bad = 1;
+      if (bad || i1 < i0 || i1 > n) bad = 1;
       else cnt = i1 - i0;
     }
     // blocks before this chunk: scan over the tile + carry
@@ -383,17 +386,21 @@ __global__ __launch_bounds__(64) void k_spec_repair(const FrameDev* __restrict__
                                                      const uint8_t* __restrict__ stream,
                                                      const QTab* __restrict__ lut, uint16_t* __restrict__ records,
                                                      uint32_t* __restrict__ nrec, uint32_t* __restrict__ wstart,
-                                                     const uint2* __restrict__ fix, const uint32_t* __restrict__ nfix) {
+                                                     uint2* __restrict__ hand, const uint2* __restrict__ fix,
+                                                     const uint32_t* __restrict__ nfix) {
   const uint32_t n = *nfix;
   for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
     const uint2 e = fix[i];
     const SpecChunkDev sc = chunks[e.x];
     const FrameDev f = frames[sc.frame];
     const uint32_t limit = (sc.c + 1u) * (uint32_t)kSpecChunk;  // where the walker's span ends
-    const uint32_t cnt = walk_record(f, stream, lut, e.y, limit, records + (size_t)e.x * kSpecCap, (uint32_t)kSpecCap);
+    uint32_t take, tail;
+    const uint32_t cnt = walk_record(f, stream, lut, e.y, sc.c * (uint32_t)kSpecChunk, limit,
+                                     records + (size_t)e.x * kSpecCap, (uint32_t)kSpecCap, take, tail);
     if (threadIdx.x == 0) {
       nrec[e.x] = cnt;
       wstart[e.x] = e.y;
+      hand[e.x] = make_uint2(take, tail);
     }
   }
 }
