@@ -12,6 +12,7 @@
  */
 #include <stdarg.h>
 #include <stdio.h>
+#include "mi_qtrtj.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -68,26 +69,59 @@ void gavl_log(int level, const char *domain, const char *fmt, ...) {
   va_end(ap);
 }
 
-int main(int argc, char **argv) {
-  if (argc < 5) return fprintf(stderr, "usage: %s packets.bin w h out.bin [skip_every]\n", argv[0]), 1;
-  const int iw = atoi(argv[2]), ih = atoi(argv[3]), skip_every = argc > 5 ? atoi(argv[5]) : 0;
-  FILE *fi = fopen(argv[1], "rb");
-  if (!fi) return perror(argv[1]), 1;
-  queue_t q = {0};
-  for (;;) {
-    uint32_t len;
-    if (fread(&len, 4, 1, fi) != 1) break;
-    q.pkts = realloc(q.pkts, sizeof(gavl_packet_t) * (q.n + 1));
-    gavl_packet_t *p = &q.pkts[q.n];
-    memset(p, 0, sizeof *p);
-    p->buf.buf = calloc(len + 64, 1); /* GAVL_PACKET_PADDING-style zero padding (lib/stream.c:487-492) */
-    p->buf.len = (int)len;
-    if (fread(p->buf.buf, 1, len, fi) != len) return fprintf(stderr, "short packet file\n"), 1;
-    p->pts = 1000 + 40 * (int64_t)q.n;
-    p->duration = 40;
-    q.n++;
+/* packets from a QuickTime file (include/mi_qtrtj.h): the role of lib/demux_quicktime.c in front of the decoder */
+static int load_mov(const char *path, queue_t *q, uint32_t *fourcc, int *w, int *h) {
+  char err[256];
+  mi_qt_reader *r = mi_qt_reader_open(path, err, sizeof err);
+  if (!r) return fprintf(stderr, "%s: %s\n", path, err), 0;
+  uint64_t n;
+  uint32_t ts;
+  mi_qt_reader_info(r, fourcc, w, h, &ts, &n);
+  q->pkts = calloc(n ? n : 1, sizeof(gavl_packet_t));
+  for (uint64_t i = 0; i < n; i++) {
+    mi_qt_sample smp;
+    mi_qt_reader_sample(r, i, &smp);
+    gavl_packet_t *p = &q->pkts[i];
+    p->buf.buf = calloc(smp.size + 64, 1);
+    p->buf.len = (int)smp.size;
+    if (mi_qt_reader_read(r, i, p->buf.buf, smp.size) != (long)smp.size) return fprintf(stderr, "%s: short sample %llu\n", path, (unsigned long long)i), 0;
+    p->pts = smp.pts;
+    p->duration = smp.duration;
+    q->n++;
   }
-  fclose(fi);
+  mi_qt_reader_close(r);
+  return 1;
+}
+
+int main(int argc, char **argv) {
+  if (argc < 5) return fprintf(stderr, "usage: %s packets.bin|movie.mov w h out.bin [skip_every]  (w h 0 0: from the movie)\n", argv[0]), 1;
+  int iw = atoi(argv[2]), ih = atoi(argv[3]);
+  const int skip_every = argc > 5 ? atoi(argv[5]) : 0;
+  queue_t q = {0};
+  uint32_t fourcc = BGAV_MK_FOURCC('R', 'T', 'J', '0');
+  const size_t plen = strlen(argv[1]);
+  if (plen > 4 && strcmp(argv[1] + plen - 4, ".mov") == 0) {
+    int mw = 0, mh = 0;
+    if (!load_mov(argv[1], &q, &fourcc, &mw, &mh)) return 1;
+    if (!iw || !ih) iw = mw, ih = mh;  /* image size from the sample description (lib/demux_quicktime.c:1515-1518) */
+  } else {
+    FILE *fi = fopen(argv[1], "rb");
+    if (!fi) return perror(argv[1]), 1;
+    for (;;) {
+      uint32_t len;
+      if (fread(&len, 4, 1, fi) != 1) break;
+      q.pkts = realloc(q.pkts, sizeof(gavl_packet_t) * (q.n + 1));
+      gavl_packet_t *p = &q.pkts[q.n];
+      memset(p, 0, sizeof *p);
+      p->buf.buf = calloc(len + 64, 1); /* GAVL_PACKET_PADDING-style zero padding (lib/stream.c:487-492) */
+      p->buf.len = (int)len;
+      if (fread(p->buf.buf, 1, len, fi) != len) return fprintf(stderr, "short packet file\n"), 1;
+      p->pts = 1000 + 40 * (int64_t)q.n;
+      p->duration = 40;
+      q.n++;
+    }
+    fclose(fi);
+  }
 
   /* bgav_codecs_init -> bgav_init_video_decoders_rtjpeg (lib/codecs.c:176) */
   bgav_init_video_decoders_rtjpeg();
@@ -95,7 +129,7 @@ int main(int argc, char **argv) {
   gavl_video_format_t fmt = {.image_width = iw, .image_height = ih};
   gavl_dictionary_t meta = {{0}}, info = {{0}};
   bgav_stream_t s = {0};
-  s.fourcc = BGAV_MK_FOURCC('R', 'T', 'J', '0');
+  s.fourcc = fourcc;
   s.m = &meta;
   s.info = &info;
   s.data.video.format = &fmt;
@@ -103,7 +137,7 @@ int main(int argc, char **argv) {
 
   /* bgav_video_start (lib/video.c:383-405) */
   bgav_video_decoder_t *dec = find_video_decoder(s.fourcc, s.info);
-  if (!dec) return fprintf(stderr, "no video decoder accepted fourcc RTJ0\n"), 3;
+  if (!dec) return fprintf(stderr, "no video decoder accepted fourcc %c%c%c%c\n", (int)(fourcc >> 24), (int)(fourcc >> 16) & 255, (int)(fourcc >> 8) & 255, (int)fourcc & 255), 3;
   if (!dec->init(&s)) return fprintf(stderr, "decoder init failed\n"), 4;
   fprintf(stderr, "decoder: %s, format %s, frame %dx%d image %dx%d\n", dec->name, meta.format, fmt.frame_width,
           fmt.frame_height, fmt.image_width, fmt.image_height);

@@ -1,0 +1,252 @@
+"""QuickTime RTJ0 container (include/mi_qtrtj.h): host C, parity unpinned
+(header of mi_qtrtj.h).  The writer's files are parsed by an independent Python walk of the atom tree
+(struct, no shared code) and by the library's own reader; malformed files must be refused with a
+message, not crash.  A GPU test plays a movie through the plugin harness."""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import rtjlib as R
+from pkg import ROOT
+
+LIB = os.path.join(ROOT, "gmerlin-avdecoder_amd", "lib", "libmi_qtrtj.so")
+
+
+class Sample(C.Structure):
+    _fields_ = [("offset", C.c_uint64), ("size", C.c_uint32), ("pts", C.c_int64), ("duration", C.c_uint32),
+                ("keyframe", C.c_int)]
+
+
+@pytest.fixture(scope="module")
+def qt():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "gmerlin-avdecoder_amd", "csrc")], check=True, capture_output=True)
+    L = C.CDLL(LIB)
+    L.mi_qt_writer_open.restype = C.c_void_p
+    L.mi_qt_writer_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_uint32, C.c_uint32]
+    L.mi_qt_writer_add.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_int]
+    L.mi_qt_writer_close.argtypes = [C.c_void_p]
+    L.mi_qt_reader_open.restype = C.c_void_p
+    L.mi_qt_reader_open.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+    L.mi_qt_reader_close.argtypes = [C.c_void_p]
+    L.mi_qt_reader_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                    C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    L.mi_qt_reader_sample.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Sample)]
+    L.mi_qt_reader_read.restype = C.c_long
+    L.mi_qt_reader_read.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_size_t]
+    return L
+
+
+def write_movie(qt, path, pkts, w, h, keys=None, timescale=30000, dur=1001):
+    wr = qt.mi_qt_writer_open(str(path).encode(), w, h, timescale, dur)
+    assert wr
+    for i, p in enumerate(pkts):
+        assert qt.mi_qt_writer_add(wr, bytes(p), len(p), 1 if keys is None else int(keys[i])) == 0
+    assert qt.mi_qt_writer_close(wr) == 0
+
+
+# ---- independent restatement: walk the atom tree with struct ----
+def atoms(buf, lo, hi):
+    while lo + 8 <= hi:
+        size, typ = struct.unpack(">I4s", buf[lo:lo + 8])
+        hdr = 8
+        if size == 1:
+            size = struct.unpack(">Q", buf[lo + 8:lo + 16])[0]
+            hdr = 16
+        elif size == 0:
+            size = hi - lo
+        assert hdr <= size <= hi - lo, (typ, size)
+        yield typ, lo + hdr, lo + size
+        lo += size
+
+
+def child(buf, lo, hi, name):
+    for t, a, b in atoms(buf, lo, hi):
+        if t == name:
+            return a, b
+    raise KeyError(name)
+
+
+def parse_movie(path):
+    buf = open(path, "rb").read()
+    top = {t: (a, b) for t, a, b in atoms(buf, 0, len(buf))}
+    assert list(t for t, _, _ in atoms(buf, 0, len(buf))) == [b"ftyp", b"mdat", b"moov"]
+    moov = top[b"moov"]
+    trak = child(buf, *moov, b"trak")
+    mdia = child(buf, *trak, b"mdia")
+    mdhd = child(buf, *mdia, b"mdhd")
+    hdlr = child(buf, *mdia, b"hdlr")
+    assert buf[hdlr[0] + 8:hdlr[0] + 12] == b"vide"
+    timescale, duration = struct.unpack(">II", buf[mdhd[0] + 12:mdhd[0] + 20])
+    stbl = child(buf, *child(buf, *mdia, b"minf"), b"stbl")
+    a, _ = child(buf, *stbl, b"stsd")
+    nent, esize, fourcc = struct.unpack(">II4s", buf[a + 4:a + 16])
+    assert nent == 1 and esize == 86
+    w, h = struct.unpack(">HH", buf[a + 8 + 32:a + 8 + 36])
+    name_len = buf[a + 8 + 50]
+    name = buf[a + 8 + 51:a + 8 + 51 + name_len]
+    a, _ = child(buf, *stbl, b"stsz")
+    fixed, n = struct.unpack(">II", buf[a + 4:a + 12])
+    sizes = list(struct.unpack(f">{n}I", buf[a + 12:a + 12 + 4 * n])) if not fixed else [fixed] * n
+    a, _ = child(buf, *stbl, b"stco")
+    nco = struct.unpack(">I", buf[a + 4:a + 8])[0]
+    offs = list(struct.unpack(f">{nco}I", buf[a + 8:a + 8 + 4 * nco]))
+    a, _ = child(buf, *stbl, b"stts")
+    runs = struct.unpack(">I", buf[a + 4:a + 8])[0]
+    tts = [struct.unpack(">II", buf[a + 8 + 8 * i:a + 16 + 8 * i]) for i in range(runs)]
+    try:
+        a, _ = child(buf, *stbl, b"stss")
+        nk = struct.unpack(">I", buf[a + 4:a + 8])[0]
+        keys = set(struct.unpack(f">{nk}I", buf[a + 8:a + 8 + 4 * nk]))
+    except KeyError:
+        keys = None
+    mdat = top[b"mdat"]
+    assert all(mdat[0] <= o and o + s <= mdat[1] for o, s in zip(offs, sizes))
+    return dict(buf=buf, fourcc=fourcc, w=w, h=h, name=name, timescale=timescale, duration=duration, sizes=sizes,
+                offs=offs, tts=tts, keys=keys)
+
+
+def test_writer_layout_and_reader_round_trip(qt, tmp_path):
+    w, h = 320, 240
+    enc = R.OracleEncoder(w, h, 200, key_rate=4, lmask=2, cmask=2)
+    pkts = [enc.encode(R.synth_frame(w, h, i // 2, seed=5, amp=4)) for i in range(9)]
+    keys = [int(p[11] == 0) for p in pkts]  # the packet header's key byte counts frames since the last key frame
+    assert 0 < sum(keys) < len(keys)
+    path = tmp_path / "a.mov"
+    write_movie(qt, path, pkts, 314, 234, keys)
+    m = parse_movie(path)
+    assert (m["fourcc"], m["w"], m["h"], m["name"], m["timescale"]) == (b"RTJ0", 314, 234, b"RTjpeg", 30000)
+    assert m["sizes"] == [p.size for p in pkts] and m["tts"] == [(9, 1001)] and m["duration"] == 9 * 1001
+    assert m["keys"] == {i + 1 for i, k in enumerate(keys) if k}
+    for o, p in zip(m["offs"], pkts):
+        assert m["buf"][o:o + p.size] == p.tobytes()
+    err = C.create_string_buffer(256)
+    r = qt.mi_qt_reader_open(str(path).encode(), err, 256)
+    assert r, err.value
+    fc, ww, hh, ts, n = C.c_uint32(), C.c_int(), C.c_int(), C.c_uint32(), C.c_uint64()
+    assert qt.mi_qt_reader_info(r, fc, ww, hh, ts, n) == 0
+    assert (fc.value, ww.value, hh.value, ts.value, n.value) == (0x52544A30, 314, 234, 30000, 9)
+    for i, p in enumerate(pkts):
+        s = Sample()
+        assert qt.mi_qt_reader_sample(r, i, s) == 0
+        assert (s.offset, s.size, s.pts, s.duration, s.keyframe) == (m["offs"][i], p.size, 1001 * i, 1001, keys[i])
+        buf = C.create_string_buffer(p.size)
+        assert qt.mi_qt_reader_read(r, i, buf, p.size) == p.size and buf.raw == p.tobytes()
+    assert qt.mi_qt_reader_sample(r, 9, Sample()) != 0
+    qt.mi_qt_reader_close(r)
+
+
+def test_all_key_frames_means_no_stss_and_empty_movie(qt, tmp_path):
+    path = tmp_path / "k.mov"
+    write_movie(qt, path, [np.arange(20, dtype=np.uint8), np.arange(7, dtype=np.uint8)], 16, 16)
+    m = parse_movie(path)
+    assert m["keys"] is None and m["sizes"] == [20, 7]
+    r = qt.mi_qt_reader_open(str(path).encode(), None, 0)
+    s = Sample()
+    assert qt.mi_qt_reader_sample(r, 1, s) == 0 and s.keyframe == 1 and s.pts == 1001
+    qt.mi_qt_reader_close(r)
+    empty = tmp_path / "e.mov"
+    write_movie(qt, empty, [], 16, 16)
+    r = qt.mi_qt_reader_open(str(empty).encode(), None, 0)
+    n = C.c_uint64(99)
+    assert r and qt.mi_qt_reader_info(r, None, None, None, None, n) == 0 and n.value == 0
+    qt.mi_qt_reader_close(r)
+
+
+def test_reader_handles_grouped_chunks_co64_and_fixed_sizes(qt, tmp_path):
+    """A file the writer would never make: three samples per chunk, 64-bit chunk offsets, one fixed
+    sample size, two stts runs, a 64-bit moov size and an unknown atom in between."""
+    payload = bytes(range(60))
+    def atom(t, body):
+        return struct.pack(">I4s", 8 + len(body), t) + body
+    stsd = atom(b"stsd", struct.pack(">II", 0, 1) + atom(b"RTJ0", bytes(6) + struct.pack(">H", 1) + struct.pack(">HH4sIIHH", 0, 0, b"test", 0, 0, 64, 48) + bytes(50)))
+    stts = atom(b"stts", struct.pack(">II", 0, 2) + struct.pack(">IIII", 4, 10, 2, 25))
+    stsc = atom(b"stsc", struct.pack(">II", 0, 1) + struct.pack(">III", 1, 3, 1))
+    stsz = atom(b"stsz", struct.pack(">III", 0, 10, 6))
+    mdat = atom(b"mdat", payload)
+    base = 8 + 8  # 'free' atom + mdat header
+    co64 = atom(b"co64", struct.pack(">II", 0, 2) + struct.pack(">QQ", base, base + 30))
+    stbl = atom(b"stbl", stsd + stts + stsc + stsz + co64)
+    mdia = atom(b"mdia", atom(b"mdhd", struct.pack(">IIIIIHH", 0, 0, 0, 600, 90, 0, 0)) +
+                atom(b"hdlr", struct.pack(">I4s4s", 0, b"mhlr", b"vide") + bytes(13)) + atom(b"minf", atom(b"junk", b"xx") + stbl))
+    audio = atom(b"trak", atom(b"mdia", atom(b"hdlr", struct.pack(">I4s4s", 0, b"mhlr", b"soun") + bytes(13))))
+    body = audio + atom(b"trak", mdia)
+    moov = struct.pack(">I4sQ", 1, b"moov", 16 + len(body)) + body
+    path = tmp_path / "g.mov"
+    path.write_bytes(atom(b"free", b"") + mdat + moov)
+    err = C.create_string_buffer(256)
+    r = qt.mi_qt_reader_open(str(path).encode(), err, 256)
+    assert r, err.value
+    n, ts = C.c_uint64(), C.c_uint32()
+    qt.mi_qt_reader_info(r, None, None, None, ts, n)
+    assert (n.value, ts.value) == (6, 600)
+    want_pts = [0, 10, 20, 30, 40, 65]
+    for i in range(6):
+        s = Sample()
+        qt.mi_qt_reader_sample(r, i, s)
+        assert (s.offset, s.size, s.pts) == (base + 10 * i, 10, want_pts[i])
+        buf = C.create_string_buffer(10)
+        assert qt.mi_qt_reader_read(r, i, buf, 10) == 10 and buf.raw == payload[10 * i:10 * i + 10]
+    qt.mi_qt_reader_close(r)
+
+
+def test_malformed_files_are_refused_with_a_message(qt, tmp_path):
+    w, h = 64, 48
+    good = tmp_path / "good.mov"
+    write_movie(qt, good, [R.OracleEncoder(w, h, 200).encode(R.synth_frame(w, h, 0))] * 3, w, h)
+    data = good.read_bytes()
+    rng = np.random.default_rng(0)
+    cases = {"empty": b"", "no_moov": data[: data.index(b"moov") - 4], "cut_in_moov": data[:-40],
+             "not_a_movie": bytes(rng.integers(0, 256, 500, dtype=np.uint8))}
+    moov = data.index(b"moov")
+    for name, pos in (("stsz_count", data.index(b"stsz") + 12), ("stco_offset", data.index(b"stco") + 12)):
+        b = bytearray(data)
+        b[pos:pos + 4] = b"\x7f\xff\xff\xff"
+        cases[name] = bytes(b)
+    for name, blob in cases.items():
+        p = tmp_path / (name + ".mov")
+        p.write_bytes(blob)
+        err = C.create_string_buffer(256)
+        assert not qt.mi_qt_reader_open(str(p).encode(), err, 256), name
+        assert err.value, name
+    for trial in range(200):  # random damage inside moov: refuse or open, never crash
+        b = bytearray(data)
+        for _ in range(int(rng.integers(1, 6))):
+            b[int(rng.integers(moov, len(b)))] = int(rng.integers(0, 256))
+        p = tmp_path / "fuzz.mov"
+        p.write_bytes(bytes(b))
+        r = qt.mi_qt_reader_open(str(p).encode(), None, 0)
+        if r:
+            n = C.c_uint64()
+            qt.mi_qt_reader_info(r, None, None, None, None, n)
+            for i in range(min(n.value, 8)):
+                s = Sample()
+                assert qt.mi_qt_reader_sample(r, i, s) == 0 and s.offset + s.size <= len(b)
+            qt.mi_qt_reader_close(r)
+
+
+@pytest.mark.gpu
+def test_movie_through_the_plugin_harness(qt, tmp_path):
+    """file -> container reader -> packet queue -> bgav_video_decoder_t -> planes: the path bgav_open()/
+    bgav_read_video() take in the reference, with this repository's pieces in the decoder's place."""
+    from test_plugin_harness import HARNESS, build_harness, expected_stream
+    build_harness()
+    w, h, iw, ih = 320, 240, 314, 234
+    enc = R.OracleEncoder(w, h, 220, 4, 2, 2)
+    pkts = [enc.encode(R.synth_frame(w, h, i // 2, seed=21, amp=4)) for i in range(7)]
+    mov, out = tmp_path / "clip.mov", tmp_path / "o.bin"
+    write_movie(qt, mov, pkts, iw, ih, [int(p[11] == 0) for p in pkts], timescale=25, dur=1)
+    r = subprocess.run([HARNESS, str(mov), "0", "0", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert f"frame {w}x{h} image {iw}x{ih}" in r.stderr
+    want = expected_stream(pkts, w, h, iw, ih, 0)
+    fsz = iw * ih + 2 * ((iw + 1) // 2) * ((ih + 1) // 2)
+    raw = np.fromfile(out, dtype=np.uint8)
+    assert raw.size == len(want) * (fsz + 8)
+    for i, (planes, _) in enumerate(want):
+        rec = raw[i * (fsz + 8):(i + 1) * (fsz + 8)]
+        assert np.array_equal(rec[:fsz], planes), i
+        assert struct.unpack("<q", rec[fsz:].tobytes())[0] == i  # pts from the stts run
