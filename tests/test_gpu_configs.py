@@ -74,3 +74,72 @@ def test_cfg5_mixed_streams_frame_scatter_over_8_ranks():
             checked += 1
         dev.close()
     assert checked == len(frames) == 128
+
+
+def test_cfg5_from_movie_files(tmp_path):
+    """The same scatter with the packets coming out of container files (QuickTime RTJ0 movies written
+    by include/mi_qtrtj.h from GPU-encoded streams), as BASELINE's 'mixed batch of files' has it."""
+    import ctypes as C
+    from test_qt_rtj0_host import Sample, write_movie
+    import subprocess, os
+    from pkg import ROOT
+    subprocess.run(["make", "-C", os.path.join(ROOT, "gmerlin-avdecoder_amd", "csrc")], check=True, capture_output=True)
+    qt = C.CDLL(os.path.join(ROOT, "gmerlin-avdecoder_amd", "lib", "libmi_qtrtj.so"))
+    qt.mi_qt_writer_open.restype = C.c_void_p
+    qt.mi_qt_writer_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_uint32, C.c_uint32]
+    qt.mi_qt_writer_add.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_int]
+    qt.mi_qt_writer_close.argtypes = [C.c_void_p]
+    qt.mi_qt_reader_open.restype = C.c_void_p
+    qt.mi_qt_reader_open.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+    qt.mi_qt_reader_close.argtypes = [C.c_void_p]
+    qt.mi_qt_reader_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                     C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    qt.mi_qt_reader_sample.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(Sample)]
+    qt.mi_qt_reader_read.restype = C.c_long
+    qt.mi_qt_reader_read.argtypes = [C.c_void_p, C.c_uint64, C.c_char_p, C.c_size_t]
+    gen = P.MiRtj()
+    files = []
+    for k, (w, h, Q, n) in enumerate([(320, 240, 64, 5), (1920, 1088, 255, 3), (640, 368, 128, 4), (320, 240, 255, 6),
+                                      (1920, 1088, 128, 2), (176, 144, 200, 7)]):
+        d_fr = gen.synth(w, h, 10 * k, n, seed=k, amp=6)
+        d_st, po, pl = gen.encode(w, h, Q, n, d_fr)  # intra-only batch: every packet a key frame
+        gen.sync()
+        pkts = [gen.d2h(d_st, int(pl[i]), offset=int(po[i])) for i in range(n)]
+        path = tmp_path / f"clip{k}.mov"
+        write_movie(qt, path, pkts, w, h - (8 if h == 1088 else 0))
+        files.append(path)
+        gen.free(d_fr)
+        gen.free(d_st)
+    gen.close()
+    frames = []  # (packet) in file order
+    for path in files:
+        r = qt.mi_qt_reader_open(str(path).encode(), None, 0)
+        assert r
+        fc, n = C.c_uint32(), C.c_uint64()
+        qt.mi_qt_reader_info(r, fc, None, None, None, n)
+        assert fc.value == 0x52544A30
+        for i in range(n.value):
+            s = Sample()
+            qt.mi_qt_reader_sample(r, i, s)
+            buf = C.create_string_buffer(s.size)
+            assert qt.mi_qt_reader_read(r, i, buf, s.size) == s.size
+            frames.append(np.frombuffer(buf.raw, dtype=np.uint8).copy())
+        qt.mi_qt_reader_close(r)
+    assert len(frames) == 27
+    world = 4
+    for rank in range(world):
+        mine = shard.frames_for_rank(len(frames), rank, world, "cyclic")
+        dev = P.MiRtj()
+        pkts = [frames[k] for k in mine]
+        d_stream, po, pl, hdrs = dev.upload_packets(pkts, align=1)
+        sizes = [fb(int(p[6]) | (int(p[7]) << 8), int(p[8]) | (int(p[9]) << 8)) for p in pkts]
+        oo = np.cumsum([0] + [(s + 255) // 256 * 256 for s in sizes[:-1]]).astype(np.uint64)
+        d_out = dev.alloc(int(oo[-1]) + sizes[-1])
+        plan = dev.plan(hdrs, po, pl, oo)
+        plan.decode(d_stream, d_out)
+        dev.sync()
+        for j, k in enumerate(mine):
+            want = np.zeros(sizes[j], np.uint8)
+            R.OracleDecoder().decode(frames[k], want)
+            assert np.array_equal(dev.d2h(d_out, sizes[j], offset=int(oo[j])), want), (rank, k)
+        dev.close()
