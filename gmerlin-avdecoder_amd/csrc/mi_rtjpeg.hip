@@ -231,7 +231,10 @@ int plan_alloc_chunks(mi_rtj_plan* p) {
       HIPCHK(c, hipMalloc((void**)&p->d_spec_wstart, sizeof(uint32_t) * p->n_spec));
       HIPCHK(c, hipMalloc((void**)&p->d_spec_hand, sizeof(uint2) * p->n_spec));
       HIPCHK(c, hipMalloc((void**)&p->d_spec_fix, sizeof(uint2) * p->n_spec));
-      if (!p->d_spec_nfix) HIPCHK(c, hipMalloc((void**)&p->d_spec_nfix, sizeof(uint32_t)));
+      if (!p->d_spec_nfix) {
+        HIPCHK(c, hipMalloc((void**)&p->d_spec_nfix, sizeof(uint32_t)));
+        HIPCHK(c, hipMemsetAsync(p->d_spec_nfix, 0, sizeof(uint32_t), c->stream));
+      }
       p->cap_spec = p->n_spec;
     }
     if ((int)p->h_frames.size() > p->cap_spec_frames) {
@@ -243,6 +246,7 @@ int plan_alloc_chunks(mi_rtj_plan* p) {
       }
       HIPCHK(c, hipMalloc((void**)&p->d_spec_base, sizeof(uint32_t) * (p->h_frames.size() + 1)));
       HIPCHK(c, hipMalloc((void**)&p->d_spec_ok, sizeof(uint32_t) * p->h_frames.size()));
+      HIPCHK(c, hipMemsetAsync(p->d_spec_ok, 0, sizeof(uint32_t) * p->h_frames.size(), c->stream));  // "nothing proven yet" for mi_rtj_plan_spec_stats
       HIPCHK(c, hipMalloc((void**)&p->d_spec_todo, sizeof(uint32_t) * (p->h_frames.size() + 1)));
       if (!p->d_spec_state) {
         HIPCHK(c, hipMalloc((void**)&p->d_spec_state, sizeof(uint32_t) * 2));
