@@ -93,7 +93,8 @@ def test_golden_inter_sequence_single_stream(dev, G):
 # --------------------------------------------------------------------------- oracle, seeded
 @pytest.mark.parametrize("w,h,Q,amp,n", [(16, 16, 255, 8, 3), (64, 48, 200, 30, 4), (320, 240, 255, 8, 6),
                                           (320, 240, 128, 64, 3), (336, 256, 1, 64, 2), (1920, 1088, 255, 8, 2),
-                                          (1920, 1088, 64, 64, 1), (4096, 16, 90, 20, 2), (16, 2048, 255, 64, 2)])
+                                          (1920, 1088, 64, 64, 1), (4096, 16, 90, 20, 2), (16, 2048, 255, 64, 2),
+                                          (65520, 16, 255, 8, 1), (16, 65520, 200, 30, 1)])  # the header's 16-bit limits
 def test_decode_matches_oracle(dev, w, h, Q, amp, n):
     enc = R.OracleEncoder(w, h, Q)
     pkts = [enc.encode(R.synth_frame(w, h, i, seed=11, amp=amp)) for i in range(n)]
