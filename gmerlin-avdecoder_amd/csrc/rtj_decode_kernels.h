@@ -277,6 +277,12 @@ __device__ __forceinline__ uint32_t px(int v) {
   return (uint32_t)s;
 }
 
+__device__ __forceinline__ uint32_t lshl_or(uint32_t a, int sh, uint32_t b) {  // (a << sh) | b
+  uint32_t r;
+  asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(sh), "v"(b));
+  return r;
+}
+
 // LDS accesses by 32-bit byte address (the parse loop keeps addresses, not indices, in registers)
 typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
 typedef __attribute__((address_space(3))) int16_t lds_i16_t;
@@ -630,8 +636,10 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
       }
       auto put_row = [&](const int (&y)[8]) {
         uint2 o;
-        o.x = px(y[0]) | (px(y[1]) << 8) | (px(y[2]) << 16) | (px(y[3]) << 24);
-        o.y = px(y[4]) | (px(y[5]) << 8) | (px(y[6]) << 16) | (px(y[7]) << 24);
+        // three shift-or instructions per four pixels, spelled out: the compiler's own choice for
+        // a | b<<8 | c<<16 | d<<24 is two shifts, an or3 and a shift-or
+        o.x = lshl_or(lshl_or(px(y[3]), 8, px(y[2])), 16, lshl_or(px(y[1]), 8, px(y[0])));
+        o.y = lshl_or(lshl_or(px(y[7]), 8, px(y[6])), 16, lshl_or(px(y[5]), 8, px(y[4])));
         *(uint2*)dst = o;
         dst += stride;
       };
