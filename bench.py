@@ -220,7 +220,7 @@ def main():
                                 "unit": "GB/s", "frac": round((dec["gbs"] or 0.0) / HBM_PEAK_GBS, 5),
                                 "ms_per_launch": dec["ms"], "alg_bytes_per_launch": alg_bytes},
             "kernels": kernels,
-            "index_mode": os.environ.get("MI_RTJ_INDEX", "parallel"),
+            "index_mode": os.environ.get("MI_RTJ_INDEX", "parallel"),  # of the exact index; see speculative_index
             "speculative_index": dict(zip(("packets_proven", "stream_chunks"), plan.spec_stats()),
                                       chunks_repaired=getattr(plan, "repaired", 0)),
             "path_gbs": round(alg_bytes * a.steps / dt / 1e9, 2),
