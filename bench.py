@@ -125,7 +125,9 @@ def main():
     # (all ranks on device 0, reduction over gloo); the real run is one rank per GPU over RCCL.
     backend = os.environ.get("MI_RTJ_DIST_BACKEND", "nccl")
     gpu = 0 if os.environ.get("MI_RTJ_SHARE_DEVICE") else local
-    if world > 1:
+    # MI_RTJ_FORCE_DIST=1: take the process-group path even with one rank (rehearses RCCL on a one-GPU box)
+    force_dist = bool(os.environ.get("MI_RTJ_FORCE_DIST"))
+    if world > 1 or force_dist:
         import torch.distributed as dist
         torch.cuda.set_device(gpu)
         if backend == "nccl":
@@ -174,7 +176,8 @@ def main():
     # the only collective of the path: SUM(frames, pixels, mismatches), MAX(elapsed) — a few bytes over RCCL
     shard = importlib.import_module("gmerlin-avdecoder_amd.shard")
     rep = shard.reduce_report(shard.Report(n, n * w * h, 0, dt), dist,
-                              device=f"cuda:{gpu}" if dist is not None and backend == "nccl" else None)
+                              device=f"cuda:{gpu}" if dist is not None and backend == "nccl" else None,
+                              force=force_dist)
     tot_frames, dt = rep.frames, rep.elapsed
 
     if rank == 0:

@@ -30,9 +30,10 @@ class Report:
     elapsed: float
 
 
-def reduce_report(local, dist=None, device=None):
-    """SUM of frames/pixels/mismatches and MAX of elapsed over all ranks; identity without dist."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+def reduce_report(local, dist=None, device=None, force=False):
+    """SUM of frames/pixels/mismatches and MAX of elapsed over all ranks; identity without dist
+    (force: run the collectives even in a group of one, to rehearse the backend)."""
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return Report(local.frames, local.pixels, local.mismatches, local.elapsed)
     import torch
     dev = device if device is not None else "cpu"
