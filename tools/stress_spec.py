@@ -52,6 +52,7 @@ def make_packet():
 
 
 t0, plans, packets, proven_total = time.time(), 0, 0, 0
+last_note = t0
 while time.time() - t0 < budget:
     pkts = [make_packet() for _ in range(int(rng.integers(1, 24)))]
     d_stream, po, pl, hdrs = dev.upload_packets(pkts, align=int(rng.choice([1, 4, 64])))
@@ -81,4 +82,7 @@ while time.time() - t0 < budget:
     dev.free(d_out)
     plans += 1
     packets += len(pkts)
+    if time.time() - last_note > 60:  # gpurun takes a silent command for hung
+        last_note = time.time()
+        print(f"... {plans} plans, {packets} packets, {last_note - t0:.0f} s", flush=True)
 print(f"stress ok: {plans} plans, {packets} packets, {proven_total} proven by the speculative index, {time.time() - t0:.0f} s")
