@@ -61,8 +61,12 @@ constexpr int kSpecFallbackRows = 64;
 constexpr int kSpecRepairGrid = 4096;   // waves of k_spec_repair (they loop over the list of chunks to walk again)
 constexpr int kSpecPauseLaunches = 64;  // launches a plan goes without speculation after two in which every packet was refused
 #ifndef MIRTJ_SPEC_VER_THREADS
-#define MIRTJ_SPEC_VER_THREADS 1024
+#define MIRTJ_SPEC_VER_THREADS 512
 #endif
+#ifndef MIRTJ_SPEC_VER_BATCH
+#define MIRTJ_SPEC_VER_BATCH 4
+#endif
+constexpr int kSpecVerBatch = MIRTJ_SPEC_VER_BATCH;  // chunks whose records a wave of k_spec_verify copies side by side
 constexpr int kSpecVerThreads = MIRTJ_SPEC_VER_THREADS;  // k_spec_verify: chunks of a packet handled side by side  // grid rows of the exact kernels when they only serve refused packets
 
 // One byte of the walker's state machine, spelled out: 17 vector instructions (the compiler's version of
@@ -345,24 +349,39 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
     // counts of refused chunks are 0, everything is clipped to the packet's own index, and the exact
     // kernels rewrite it)
     const uint32_t tile_n = min((uint32_t)kSpecVerThreads, nsc - c0);
-    for (uint32_t j = (uint32_t)wv; j < tile_n; j += kSpecVerThreads / 64) {
-      const uint32_t cj = c0 + j, base = s_base[j];
-      if (base > last) break;  // bases ascend
-      const uint32_t m = min(s_cnt[j], last + 1u - base);
-      const uint32_t start = wstart[sc0 + cj];
-      const uint16_t* R = records + (size_t)(sc0 + cj) * kSpecCap + s_i0[j];
-      // a chunk holds ~200 blocks: four loads in flight per lane, so that a chunk costs one round trip
-      for (uint32_t k0 = 0; k0 < m; k0 += 256) {
-        uint32_t v[4];
+    // A chunk holds ~200 blocks, i.e. one round trip of four 2-byte gathers per lane; a wave works on
+    // kSpecVerBatch chunks at a time so that it waits for memory once per batch, not once per chunk.
+    constexpr uint32_t kWaves = kSpecVerThreads / 64;
+    for (uint32_t j0 = (uint32_t)wv; j0 < tile_n; j0 += kSpecVerBatch * kWaves) {
+      uint32_t base[kSpecVerBatch], m[kSpecVerBatch], start[kSpecVerBatch], mmax = 0;
+      const uint16_t* R[kSpecVerBatch];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const uint32_t k = k0 + 64u * (uint32_t)u + (uint32_t)lane;
-          v[u] = k < m ? R[k] : 0u;
+      for (int u = 0; u < kSpecVerBatch; u++) {
+        const uint32_t j = min(j0 + (uint32_t)u * kWaves, tile_n - 1u);
+        const bool have = j0 + (uint32_t)u * kWaves < tile_n;
+        base[u] = s_base[j];
+        m[u] = have && base[u] <= last ? min(s_cnt[j], last + 1u - base[u]) : 0u;  // clipped to the packet's own index
+        start[u] = wstart[sc0 + c0 + j];
+        R[u] = records + (size_t)(sc0 + c0 + j) * kSpecCap + s_i0[j];
+        mmax = max(mmax, m[u]);
+      }
+      for (uint32_t k0 = 0; k0 < mmax; k0 += 256) {
+        uint32_t v[kSpecVerBatch][4];
+#pragma unroll
+        for (int u = 0; u < kSpecVerBatch; u++) {
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            const uint32_t k = k0 + 64u * (uint32_t)t + (uint32_t)lane;
+            v[u][t] = k < m[u] ? R[u][k] : 0u;
+          }
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const uint32_t k = k0 + 64u * (uint32_t)u + (uint32_t)lane;
-          if (k < m) out[base + k] = start + v[u];
+        for (int u = 0; u < kSpecVerBatch; u++) {
+#pragma unroll
+          for (int t = 0; t < 4; t++) {
+            const uint32_t k = k0 + 64u * (uint32_t)t + (uint32_t)lane;
+            if (k < m[u]) out[base[u] + k] = start[u] + v[u][t];
+          }
         }
       }
     }
