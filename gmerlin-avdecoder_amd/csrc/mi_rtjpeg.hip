@@ -72,7 +72,7 @@ struct mi_rtj_plan {
   bool emit_walk = false;           // MI_RTJ_EMIT=walk: per-chunk re-walk instead of the length tables
   bool one_block_type = false;      // every frame's tables have lb8 == cb8: single-search summarize
   // speculative index (rtj_spec_kernels.h): one walker per kSpecChunk bytes, proven per packet afterwards
-  int spec_mode = -1;               // MI_RTJ_SPEC: 0 never, 1 always (no pausing), 2 whatever the batch size, otherwise by batch size
+  int spec_mode = -1;               // MI_RTJ_SPEC: 0 never, 1 / 3 always with the short / long lead (no policy), 2 whatever the batch size, otherwise by batch size
   bool spec = false;
   uint64_t n_spec = 0, cap_spec = 0;       // walkers of this plan / allocated
   std::vector<SpecChunkDev> h_spec_chunks;
@@ -249,8 +249,8 @@ int plan_alloc_chunks(mi_rtj_plan* p) {
       HIPCHK(c, hipMemsetAsync(p->d_spec_ok, 0, sizeof(uint32_t) * p->h_frames.size(), c->stream));  // "nothing proven yet" for mi_rtj_plan_spec_stats
       HIPCHK(c, hipMalloc((void**)&p->d_spec_todo, sizeof(uint32_t) * (p->h_frames.size() + 1)));
       if (!p->d_spec_state) {
-        HIPCHK(c, hipMalloc((void**)&p->d_spec_state, sizeof(uint32_t) * 2));
-        HIPCHK(c, hipMemsetAsync(p->d_spec_state, 0, sizeof(uint32_t) * 2, c->stream));
+        HIPCHK(c, hipMalloc((void**)&p->d_spec_state, sizeof(uint32_t) * kSpecStWords));
+        HIPCHK(c, hipMemsetAsync(p->d_spec_state, 0, sizeof(uint32_t) * kSpecStWords, c->stream));
       }
       p->cap_spec_frames = (int)p->h_frames.size();
     }
@@ -307,7 +307,8 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
     // noisy content defeats the speculation; a plan that sees every packet refused twice in a row goes
     // without it for kSpecPauseLaunches launches.  The policy lives on the device (k_spec_policy), so it
     // also works when launches are queued faster than they run.
-    uint32_t* const state = p->spec_mode == 1 ? nullptr : p->d_spec_state;
+    const bool no_policy = p->spec_mode == 1 || p->spec_mode == 3;  // always speculate: short (1) or long (3) lead
+    uint32_t* const state = no_policy ? nullptr : p->d_spec_state;
     if (spec) {
       ntodo = p->d_spec_todo;
       todo = p->d_spec_todo + 1;
@@ -315,12 +316,20 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
       HIPCHK(c, hipMemsetAsync(p->d_spec_todo, 0, sizeof(uint32_t), c->stream));
       HIPCHK(c, hipMemsetAsync(p->d_spec_nfix, 0, sizeof(uint32_t), c->stream));
       if ((rc = begin(MI_RTJ_K_SPEC_WALK)) != MI_RTJ_OK) return rc;
-      if (p->one_block_type)
-        hipLaunchKernelGGL(k_spec_walk<false>, dim3((unsigned)((p->n_spec + 63) / 64)), dim3(64), 0, c->stream, p->d_frames,
-                           p->d_spec_chunks, (uint32_t)p->n_spec, st, c->d_lut, p->d_spec_rec, p->d_spec_nrec, p->d_spec_wstart, p->d_spec_hand, state);
-      else
-        hipLaunchKernelGGL(k_spec_walk<true>, dim3((unsigned)((p->n_spec + 63) / 64)), dim3(64), 0, c->stream, p->d_frames,
-                           p->d_spec_chunks, (uint32_t)p->n_spec, st, c->d_lut, p->d_spec_rec, p->d_spec_nrec, p->d_spec_wstart, p->d_spec_hand, state);
+      // both walker forms (short and long lead) are queued; the one the policy state does not name returns at once
+      const dim3 wgrid((unsigned)((p->n_spec + 63) / 64));
+#define MIRTJ_LAUNCH_WALK(PHASE, LEAD)                                                                                  \
+  hipLaunchKernelGGL((k_spec_walk<PHASE, LEAD>), wgrid, dim3(64), 0, c->stream, p->d_frames, p->d_spec_chunks,         \
+                     (uint32_t)p->n_spec, st, c->d_lut, p->d_spec_rec, p->d_spec_nrec, p->d_spec_wstart, p->d_spec_hand, \
+                     state)
+      if (p->one_block_type) {
+        if (p->spec_mode != 3) MIRTJ_LAUNCH_WALK(false, kSpecLead);
+        if (state || p->spec_mode == 3) MIRTJ_LAUNCH_WALK(false, kSpecLeadLong);
+      } else {
+        if (p->spec_mode != 3) MIRTJ_LAUNCH_WALK(true, kSpecLead);
+        if (state || p->spec_mode == 3) MIRTJ_LAUNCH_WALK(true, kSpecLeadLong);
+      }
+#undef MIRTJ_LAUNCH_WALK
       if ((rc = end(MI_RTJ_K_SPEC_WALK)) != MI_RTJ_OK) return rc;
       if ((rc = begin(MI_RTJ_K_SPEC_VERIFY)) != MI_RTJ_OK) return rc;
       // first pass; walkers that had not fallen into step are walked again from a known block start; second
@@ -637,6 +646,23 @@ int mi_rtj_plan_times(mi_rtj_plan* p, float ms[MI_RTJ_NUM_KERNELS], int* launche
     }
   }
   if (launches) *launches = (int)p->ev[MI_RTJ_K_DECODE].size();
+  return MI_RTJ_OK;
+}
+
+int mi_rtj_plan_spec_lead(mi_rtj_plan* p, int* lead_bytes, int* paused_launches) {
+  if (!p || !lead_bytes || !paused_launches) return MI_RTJ_ERR_ARG;
+  mi_rtj_ctx* c = p->ctx;
+  *lead_bytes = 0;
+  *paused_launches = 0;
+  if (!p->spec) return MI_RTJ_OK;
+  *lead_bytes = p->spec_mode == 3 ? kSpecLeadLong : kSpecLead;
+  if (p->spec_mode == 1 || p->spec_mode == 3 || !p->d_spec_state) return MI_RTJ_OK;  // no policy
+  uint32_t st[kSpecStWords];
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(st, p->d_spec_state, sizeof(st), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *lead_bytes = st[kSpecStLong] ? kSpecLeadLong : kSpecLead;
+  *paused_launches = (int)st[kSpecStPause];
   return MI_RTJ_OK;
 }
 

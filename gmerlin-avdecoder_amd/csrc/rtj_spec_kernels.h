@@ -42,7 +42,11 @@ namespace mirtj {
 
 constexpr int kSpecChunk = MIRTJ_SPEC_CHUNK;  // stream bytes a walker owns
 constexpr int kSpecLead = MIRTJ_SPEC_LEAD;   // bytes it parses before them, from an assumed macroblock start
-constexpr int kSpecSpan = kSpecLead + kSpecChunk;
+#ifndef MIRTJ_SPEC_LEAD_LONG
+#define MIRTJ_SPEC_LEAD_LONG 1536
+#endif
+constexpr int kSpecLeadLong = MIRTJ_SPEC_LEAD_LONG;  // the lead of the second walker form, for content that falls into step late
+constexpr int kSpecSpan = kSpecLeadLong + kSpecChunk;  // the longest span a walker parses
 constexpr int kSpecTile = 128;    // bytes per lane fetched at a time (one cache line)
 constexpr int kSpecCap = 2048;    // block starts a walker can record (16-bit, relative to its first byte):
                                   // enough for blocks of 1.75 bytes on average over its span
@@ -52,6 +56,8 @@ constexpr int kSpecRingRow = 64 + 16;       // LDS bytes per lane of the record 
 constexpr int kSpecRow = kSpecTile + 16;  // LDS bytes per lane: tile + the dword after it + bank padding
 static_assert(kSpecSpan % kSpecTile == 0 && kSpecSpan < 65536, "walker span: whole tiles, 16-bit positions");
 static_assert(kSpecLead >= 6 * 64 + 64 && kSpecLead % kSpecTile == 0 && kSpecChunk % kSpecTile == 0, "the lead: at least one whole macroblock, whole tiles");
+static_assert(kSpecLeadLong >= kSpecLead && kSpecLeadLong % kSpecTile == 0 && kSpecLeadLong <= kSpecChunk,
+              "a walker starts inside the chunk before its own (chunk 1's walker at byte kSpecChunk - lead >= 0)");
 
 struct SpecChunkDev {
   uint32_t frame;  // index into the plan's frames
@@ -60,6 +66,13 @@ struct SpecChunkDev {
 constexpr int kSpecFallbackRows = 64;
 constexpr int kSpecRepairGrid = 4096;   // waves of k_spec_repair (they loop over the list of chunks to walk again)
 constexpr int kSpecPauseLaunches = 64;  // launches a plan goes without speculation after two in which every packet was refused
+// k_spec_policy's state words (per plan, on the device)
+enum { kSpecStLost = 0,    // launches in a row that were lost
+       kSpecStPause = 1,   // launches left without speculation
+       kSpecStLong = 2,    // 1: the walkers use the long lead
+       kSpecStQuiet = 3,   // long lead: launches in a row that needed next to no repairs
+       kSpecStWords = 4 };
+constexpr int kSpecQuietLaunches = 16;  // that many of them in a row and the plan tries the short lead again
 #ifndef MIRTJ_SPEC_VER_THREADS
 #define MIRTJ_SPEC_VER_THREADS 512
 #endif
@@ -125,14 +138,17 @@ constexpr int kSpecVerThreads = MIRTJ_SPEC_VER_THREADS;  // k_spec_verify: chunk
       : [w] "v"(w_), [k63] "v"(k63), [kn64] "v"(kn64), [ring] "v"(ring_a), [val] "v"(val_), [rb] "v"(rb)           \
       : "vcc", "memory")
 
-template <bool PHASE>
+template <bool PHASE, int LEAD>
 __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ frames,
                                                    const SpecChunkDev* __restrict__ chunks, uint32_t total,
                                                    const uint8_t* __restrict__ stream,
                                                    const QTab* __restrict__ lut, uint16_t* __restrict__ records,
                                                    uint32_t* __restrict__ nrec, uint32_t* __restrict__ wstart,
                                                    uint2* __restrict__ hand, const uint32_t* __restrict__ state) {
-  if (state && state[1]) return;  // paused (k_spec_policy)
+  // both forms are launched; the plan's policy state says which one works (none while paused, k_spec_policy)
+  if (state && (state[kSpecStPause] || (state[kSpecStLong] != 0u) != (LEAD != kSpecLead))) return;
+  constexpr int kSpan = LEAD + kSpecChunk;
+  static_assert(kSpan % kSpecTile == 0 && kSpan < 65536, "walker span: whole tiles, 16-bit positions");
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[64 * kSpecRingRow];
   const int lane = threadIdx.x;
   const uint32_t g = blockIdx.x * 64u + (uint32_t)lane;
@@ -140,7 +156,7 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
   const SpecChunkDev sc = chunks[act ? g : total - 1u];  // idle lanes shadow the last chunk and store nothing
   const FrameDev f = frames[sc.frame];
   const int lb = lut[f.qidx].lb8 + 1, cb = lut[f.qidx].cb8 + 1;  // DC + raw bytes of a luma / chroma block
-  const uint32_t start = sc.c ? sc.c * (uint32_t)kSpecChunk - (uint32_t)kSpecLead : 0u;  // first byte parsed
+  const uint32_t start = sc.c ? sc.c * (uint32_t)kSpecChunk - (uint32_t)LEAD : 0u;  // first byte parsed
   const uint8_t* gp = stream + f.data_off + start;
   const uint32_t sh = (uint32_t)((uintptr_t)gp & 3u);
   const uint32_t* g4 = (const uint32_t*)(gp - sh);
@@ -215,18 +231,18 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
   uint32_t tail0 = 0;
 
   request(0);
-  for (int t = 0; t < kSpecSpan / kSpecTile; t++) {
+  for (int t = 0; t < kSpan / kSpecTile; t++) {
     // the tile is parsed out of registers (fully unrolled: 128 byte steps); staging it in LDS for a
     // smaller loop body capped the kernel at 11 waves per CU
-    if (t == kSpecLead / kSpecTile) {  // the chunk begins with this tile
-      const uint32_t v = last_aligned_below((uint32_t)kSpecLead);
+    if (t == LEAD / kSpecTile) {  // the chunk begins with this tile
+      const uint32_t v = last_aligned_below((uint32_t)LEAD);
       take = sc.c ? v : 0u;
     }
     if (t == kSpecChunk / kSpecTile) tail0 = last_aligned_below((uint32_t)kSpecChunk);  // chunk 0 (no lead) ends here
     uint32_t cur[33];
 #pragma unroll
     for (int k = 0; k < 33; k++) cur[k] = buf[k];
-    if (t + 1 < kSpecSpan / kSpecTile) request(t + 1);  // in flight while this tile is parsed
+    if (t + 1 < kSpan / kSpecTile) request(t + 1);  // in flight while this tile is parsed
 #pragma unroll
     for (int i = 0; i < kSpecTile / 16; i++) {
       const uint32_t wd[4] = {__builtin_amdgcn_alignbyte(cur[4 * i + 1], cur[4 * i], sh),
@@ -263,7 +279,7 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
   if (act) {
     nrec[g] = cnt;  // > kSpecCap: the span held more blocks than a walker records
     wstart[g] = start;
-    const uint32_t tail = last_aligned_below((uint32_t)kSpecSpan);
+    const uint32_t tail = last_aligned_below((uint32_t)kSpan);
     hand[g] = make_uint2(take, sc.c ? tail : tail0);  // .y: what the next chunk must take over from
   }
 }
@@ -281,7 +297,7 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
                                                       const uint32_t* __restrict__ wstart,
                                                       const uint2* __restrict__ hand, uint2* __restrict__ fix,
                                                       uint32_t* __restrict__ nfix, int pass) {
-  if (state && state[1]) {  // paused (k_spec_policy): nothing was walked, nothing is proven
+  if (state && state[kSpecStPause]) {  // paused (k_spec_policy): nothing was walked, nothing is proven
     if (threadIdx.x == 0) ok[blockIdx.x] = 0;
     return;
   }
@@ -425,27 +441,43 @@ __global__ __launch_bounds__(64) void k_spec_repair(const FrameDev* __restrict__
 }
 
 
-// After k_spec_verify, one workgroup.  todo_cnt[0] = packets refused in this launch, todo_cnt[1..] = the list;
-// state[0] = launches in a row that were lost (see below), state[1] = launches left without speculation.
-// While paused k_spec_walk and k_spec_verify return at once and this kernel puts every packet on the list.
+// After k_spec_verify, one workgroup.  todo_cnt[0] = packets refused in this launch, todo_cnt[1..] = the list.
+// The plan's walkers start with the short lead.  A launch in which more than 1/32 of them had to be walked
+// again (or that was lost, see below) moves the plan to the long lead: twice the bytes before each chunk to
+// fall into step in, a quarter more to parse.  With the long lead, kSpecQuietLaunches launches in a row that
+// needed next to no repairs (under 1/32768 of the walkers: what content that is comfortable with the short
+// lead shows; a small batch shows it on any content, hence the run length) move it back;
+// two lost launches in a row pause the speculation for kSpecPauseLaunches launches, during which both walkers
+// and k_spec_verify return at once and this kernel puts every packet on the exact kernels' list.
 __global__ __launch_bounds__(256) void k_spec_policy(uint32_t n, uint32_t walkers, uint32_t* __restrict__ todo_cnt,
                                                       const uint32_t* __restrict__ nfix, uint32_t* __restrict__ state) {
-  const uint32_t pause = state[1];
+  const uint32_t pause = state[kSpecStPause];
   if (pause) {
     for (uint32_t i = threadIdx.x; i < n; i += 256) todo_cnt[1 + i] = i;
     __syncthreads();
     if (threadIdx.x == 0) {
       todo_cnt[0] = n;
-      state[1] = pause - 1u;
-      if (pause == 1u) state[0] = 1u;  // one more lost launch pauses again
+      state[kSpecStPause] = pause - 1u;
+      if (pause == 1u) state[kSpecStLost] = 1u;  // one more lost launch pauses again
     }
   } else if (threadIdx.x == 0) {
     // a lost launch: every packet refused, or so many walkers repaired (one wave each) that the exact
     // kernels would have been quicker
-    const bool lost = todo_cnt[0] == n || 4u * *nfix > walkers;
-    const uint32_t streak = lost ? state[0] + 1u : 0u;
-    state[0] = streak;
-    if (streak >= 2u) state[1] = (uint32_t)kSpecPauseLaunches;
+    const uint32_t nf = *nfix;
+    const bool lost = todo_cnt[0] == n || 4u * (uint64_t)nf > walkers;
+    if (!state[kSpecStLong]) {
+      if (lost || 32u * (uint64_t)nf > walkers) {
+        state[kSpecStLong] = 1u;
+        state[kSpecStQuiet] = 0u;
+      }
+    } else {
+      const uint32_t streak = lost ? state[kSpecStLost] + 1u : 0u;
+      state[kSpecStLost] = streak;
+      if (streak >= 2u) state[kSpecStPause] = (uint32_t)kSpecPauseLaunches;
+      const uint32_t quiet = !lost && 32768u * (uint64_t)nf < walkers ? state[kSpecStQuiet] + 1u : 0u;
+      state[kSpecStQuiet] = quiet;
+      if (quiet >= (uint32_t)kSpecQuietLaunches) state[kSpecStLong] = 0u;
+    }
   }
 }
 

@@ -113,6 +113,10 @@ int mi_rtj_plan_times(mi_rtj_plan *plan, float ms[MI_RTJ_NUM_KERNELS], int *laun
  * accepted (the others were indexed by the exact kernels), *repaired = chunks that were walked a second
  * time before that.  Synchronises the instance's stream. */
 int mi_rtj_plan_spec_stats(mi_rtj_plan *plan, int *proven, long long *walkers, long long *repaired);
+/* What the plan's device-side policy has decided for the NEXT decode: *lead_bytes = bytes each walker parses
+ * before its chunk (the short or the long form; 0: the speculative index is not used for this plan),
+ * *paused_launches = decodes left that go straight to the exact kernels.  Synchronises the instance's stream. */
+int mi_rtj_plan_spec_lead(mi_rtj_plan *plan, int *lead_bytes, int *paused_launches);
 /* Test hook: copy the plan's block-start index (relative to each packet's first data byte,
  * nblocks+1 entries per frame, frames back to back) to the host after a decode. */
 int mi_rtj_plan_read_index(mi_rtj_plan *plan, uint32_t *dst, size_t max_entries);

@@ -1,4 +1,4 @@
-"""The speculative block index (csrc/rtj_spec_kernels.h) is switched on by batch size; MI_RTJ_SPEC=1
+"""The speculative block index (csrc/rtj_spec_kernels.h) is switched on by batch size; MI_RTJ_SPEC=1 / 3
 forces it for every plan, also the one-packet path.  The parity tests are run again that way: streams
 an encoder made must come out of the speculative path (the exact kernels then skip the packet),
 adversarial ones must be rejected by its proof step and indexed by the exact kernels — either way the
@@ -13,9 +13,9 @@ from pkg import P
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture()
-def dev(monkeypatch):
-    monkeypatch.setenv("MI_RTJ_SPEC", "1")
+@pytest.fixture(params=["1", "3"], ids=["short-lead", "long-lead"])
+def dev(monkeypatch, request):
+    monkeypatch.setenv("MI_RTJ_SPEC", request.param)  # always speculate, no policy: 1 the short lead, 3 the long one
     d = P.MiRtj()
     yield d
     d.close()
@@ -46,8 +46,7 @@ def test_mixed_batches_skip_blocks_truncation_and_fuzz(dev):
     T.test_low_4x4_transform_path_and_its_boundary(dev)
 
 
-def test_one_packet_path_and_inter_stream(dev, G, monkeypatch):
-    monkeypatch.setenv("MI_RTJ_SPEC", "1")
+def test_one_packet_path_and_inter_stream(dev, G):
     T.test_golden_inter_sequence_single_stream(dev, G)
     T.test_random_token_streams(dev)
     T.test_quality_zero_state_machine(dev)
@@ -86,9 +85,10 @@ def test_speculation_is_taken_or_refused_as_expected(dev):
 
 
 def test_plans_that_keep_being_refused_pause_the_speculation(monkeypatch):
-    """Device-side policy (k_spec_policy): after two launches in which every packet was refused the
-    walkers return at once for a while; results do not change.  MI_RTJ_SPEC=2 switches the speculation
-    on regardless of the batch size but, unlike =1, leaves the policy active."""
+    """Device-side policy (k_spec_policy): a launch in which every packet was refused moves the plan to the
+    walkers with the long lead; after two such launches with those, both walkers return at once for a while;
+    results do not change.  MI_RTJ_SPEC=2 switches the speculation on regardless of the batch size but,
+    unlike =1, leaves the policy active."""
     monkeypatch.setenv("MI_RTJ_SPEC", "2")
     d = P.MiRtj()
     w, h, n = 640, 368, 300000
@@ -106,17 +106,21 @@ def test_plans_that_keep_being_refused_pause_the_speculation(monkeypatch):
         x = np.zeros(fsz, np.uint8)
         dec.decode(p, x)
         want.append(x)
-    walk = []
-    for it in range(6):
+    walk, lead = [], [plan.spec_lead()]
+    for it in range(7):
         d.memset(d_out, 0, fsz * len(pkts))
         plan.profile(True)
         plan.decode(d_stream, d_out)
         ms, _ = plan.times()
         walk.append(ms["k_spec_walk"])
         assert plan.spec_stats()[0] == 0
+        lead.append(plan.spec_lead())
         for i in range(len(pkts)):
             assert np.array_equal(d.d2h(d_out, fsz, offset=i * fsz), want[i]), (it, i)
-    assert min(walk[:2]) > 5 * max(walk[2:]), walk
+    assert min(walk[:3]) > 5 * max(walk[3:]), walk
+    short, long_ = lead[0][0], lead[1][0]
+    assert 0 < short < long_, lead
+    assert [x[0] for x in lead[1:]] == [long_] * 7 and lead[1][1] == lead[2][1] == 0 and lead[3][1] > lead[4][1] > 0, lead
     plan.close()
     d.free(d_stream)
     d.free(d_out)
@@ -172,3 +176,46 @@ def test_walkers_that_lock_late_are_repaired(dev):
     plan.close()
     dev.free(d_stream)
     dev.free(d_out)
+
+
+def test_content_that_locks_late_moves_the_plan_to_the_long_lead(monkeypatch):
+    """Noise of +-22 at Q=255: with the short lead about one walker in six has to be walked again, so the
+    policy moves the plan to the long lead for the next decode; pictures equal the oracle's either way, and
+    after enough decodes in a row without any repair the plan tries the short lead again."""
+    monkeypatch.setenv("MI_RTJ_SPEC", "2")
+    d = P.MiRtj()
+    w, h = 1920, 1088
+    pkts = [R.OracleEncoder(w, h, 255).encode(R.synth_frame(w, h, i, amp=22)) for i in range(3)]
+    d_stream, po, pl, hdrs = d.upload_packets(pkts, align=1)
+    fsz = T.frame_bytes(w, h)
+    d_out = d.alloc(fsz * len(pkts))
+    plan = d.plan(hdrs, po, pl, np.arange(len(pkts), dtype=np.uint64) * np.uint64(fsz))
+    want = []
+    for p in pkts:
+        x = np.zeros(fsz, np.uint8)
+        R.OracleDecoder().decode(p, x)
+        want.append(x)
+    short = plan.spec_lead()[0]
+    leads, repaired, proven = [], [], []
+    for it in range(20):
+        d.memset(d_out, 0, fsz * len(pkts))
+        plan.decode(d_stream, d_out)
+        proven.append(plan.spec_stats()[0])
+        repaired.append(plan.repaired)
+        leads.append(plan.spec_lead()[0])
+        if it in (0, 1, 17, 18, 19):
+            for i in range(len(pkts)):
+                assert np.array_equal(d.d2h(d_out, fsz, offset=i * fsz), want[i]), (it, i)
+    assert leads[0] > short, (short, leads)           # the first decode saw many repairs
+    assert repaired[0] > 8 * max(1, repaired[1]), repaired  # the long lead needs few
+    assert proven[1] == len(pkts), proven
+    if repaired[1] == 0:  # the same packets every time: all decodes with the long lead are alike
+        assert short in leads[1:], leads              # quiet long enough: back to the short lead ...
+        k = leads.index(short, 1)
+        assert leads[k + 1] > short, leads            # ... which at once shows why it was left
+    else:
+        assert short not in leads, leads              # a repair in 1760 walkers is not quiet: the long lead stays
+    plan.close()
+    d.free(d_stream)
+    d.free(d_out)
+    d.close()

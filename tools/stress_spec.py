@@ -2,9 +2,10 @@
 """Randomised differential run of the speculative index (forced on) against the CPU oracle: many small
 plans of mixed packets — encoder-made at random quality/noise, with unchanged (0xFF) blocks, cut short at
 lengths around the walker chunk size, random bytes, runs of tiny blocks.  Not part of the test suite
-(minutes); run on the GPU box: python tools/stress_spec.py [seconds] [seed]."""
+(minutes); run on the GPU box: python tools/stress_spec.py [seconds] [seed] [MI_RTJ_SPEC mode]."""
 import os, sys, time
-os.environ["MI_RTJ_SPEC"] = "1"
+
+os.environ["MI_RTJ_SPEC"] = sys.argv[3] if len(sys.argv) > 3 else "1"  # 1: short lead, 3: long lead, 2: with the policy
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
