@@ -225,7 +225,8 @@ def main():
             "kernels": kernels,
             "index_mode": os.environ.get("MI_RTJ_INDEX", "parallel"),  # of the exact index; see speculative_index
             "speculative_index": dict(zip(("packets_proven", "stream_chunks"), plan.spec_stats()),
-                                      chunks_repaired=getattr(plan, "repaired", 0)),
+                                      chunks_repaired=getattr(plan, "repaired", 0),
+                                      walker_lead_bytes=plan.spec_lead()[0]),  # what the policy chose for the next launch
             "path_gbs": round(alg_bytes * a.steps / dt / 1e9, 2),
         }
         if world == 1 and not a.no_cpu:
