@@ -267,6 +267,22 @@ __device__ __forceinline__ void idct8_lo(int x0, int x1, int x2, int x3, int (&y
   y[4] = e3 + o4; y[3] = e3 - o4;
 }
 
+// The same again when x3 is zero as well (mulr8(0, 669) == 0), for waves whose blocks stay inside the low 3x3:
+// chroma at high quality.
+__device__ __forceinline__ void idct8_lo3(int x0, int x1, int x2, int (&y)[8]) {
+  const int r26 = mulr8(x2, 362) - x2;
+  const int e0 = x0 + x2, e3 = x0 - x2, e1 = x0 + r26, e2 = x0 - r26;
+  const int m = mulr8(x1, 362);
+  const int z5 = mulr8(x1, 473);
+  const int o6 = z5 - x1;
+  const int o5 = m - o6;
+  const int o4 = mulr8(x1, 277) - z5 + o5;
+  y[0] = e0 + x1; y[7] = e0 - x1;
+  y[1] = e1 + o6; y[6] = e1 - o6;
+  y[2] = e2 + o5; y[5] = e2 - o5;
+  y[4] = e3 + o4; y[3] = e3 - o4;
+}
+
 // DESCALE + int16 narrowing + clamp 16..235 (lib/RTjpeg.c:1201-1205).  The +4 rounding term
 // was folded into the DC coefficient before the column pass, so only the shift remains:
 // bits [18:3] sign-extended == (int16_t)(v >> 3).
@@ -645,24 +661,49 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
       };
 
       if (lo) {
-        // ---- four-input transform: columns 0-3 in, rows of four in ----
-        int ws[8][4];
+        uint2 ql[4];
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-          const uint2 q = *(const uint2*)((const uint8_t*)my + 16 * c);
-          int x0 = (int)(int16_t)(q.x & 0xFFFFu);
-          const int x1 = (int)q.x >> 16, x2 = (int)(int16_t)(q.y & 0xFFFFu), x3 = (int)q.y >> 16;
-          if (c == 0) x0 += 4;  // DESCALE's rounding term, carried through both linear DC paths
-          int y[8];
-          idct8_lo(x0, x1, x2, x3, y);
+        for (int c = 0; c < 4; c++) ql[c] = *(const uint2*)((const uint8_t*)my + 16 * c);
+        // anything in row 3 or column 3?  (the lanes of this branch: those with a live block)
+        const uint32_t t3 = ql[3].x | ql[3].y | ((ql[0].y | ql[1].y | ql[2].y) & 0xFFFF0000u);
+        if (!__any(t3 != 0u)) {
+          // ---- three-input transform: columns 0-2 in, rows of three in ----
+          int ws[8][3];
 #pragma unroll
-          for (int r = 0; r < 8; r++) ws[r][c] = y[r];
-        }
+          for (int c = 0; c < 3; c++) {
+            int x0 = (int)(int16_t)(ql[c].x & 0xFFFFu);
+            const int x1 = (int)ql[c].x >> 16, x2 = (int)(int16_t)(ql[c].y & 0xFFFFu);
+            if (c == 0) x0 += 4;  // DESCALE's rounding term, carried through both linear DC paths
+            int y[8];
+            idct8_lo3(x0, x1, x2, y);
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-          int y[8];
-          idct8_lo(ws[r][0], ws[r][1], ws[r][2], ws[r][3], y);
-          put_row(y);
+            for (int r = 0; r < 8; r++) ws[r][c] = y[r];
+          }
+#pragma unroll
+          for (int r = 0; r < 8; r++) {
+            int y[8];
+            idct8_lo3(ws[r][0], ws[r][1], ws[r][2], y);
+            put_row(y);
+          }
+        } else {
+          // ---- four-input transform: columns 0-3 in, rows of four in ----
+          int ws[8][4];
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            int x0 = (int)(int16_t)(ql[c].x & 0xFFFFu);
+            const int x1 = (int)ql[c].x >> 16, x2 = (int)(int16_t)(ql[c].y & 0xFFFFu), x3 = (int)ql[c].y >> 16;
+            if (c == 0) x0 += 4;  // DESCALE's rounding term, carried through both linear DC paths
+            int y[8];
+            idct8_lo(x0, x1, x2, x3, y);
+#pragma unroll
+            for (int r = 0; r < 8; r++) ws[r][c] = y[r];
+          }
+#pragma unroll
+          for (int r = 0; r < 8; r++) {
+            int y[8];
+            idct8_lo(ws[r][0], ws[r][1], ws[r][2], ws[r][3], y);
+            put_row(y);
+          }
         }
       } else {
         // ---- column pass: column c of the block is the c-th 16-byte piece of the scratch ----

@@ -345,14 +345,15 @@ def _packet_from_blocks(w, h, Q, blocks):
 
 def test_low_4x4_transform_path_and_its_boundary(dev):
     """k_decode runs a four-input transform when no block of a wave has a coefficient outside the low
-    4x4.  Packets are built so that whole waves qualify, whole waves do not, a wave stops qualifying from
+    4x4, and a three-input one when none reaches row 3 or column 3 either.  Packets are built so that whole waves qualify, whole waves do not, a wave stops qualifying from
     one macroblock group to the next, and the single coefficient sits on every one of the 63 AC slots
     (inside, on the edge of and outside the 4x4) with values where the int16 narrowing shows."""
     rng = np.random.default_rng(99)
     pkts = []
     for Q in (255, 200, 150, 3):
         _, _, lb8, cb8, _, _ = R.oracle_tables(Q)
-        for (w, h, mode) in ((512, 64, "one"), (1024, 32, "flat_then_busy"), (512, 32, "dc_only")):
+        for (w, h, mode) in ((512, 64, "one"), (1024, 32, "flat_then_busy"), (512, 32, "dc_only"),
+                             (1024, 48, "three_then_four")):
             nmb = (w // 16) * (h // 16)
             blocks = []
             for mb in range(nmb):
@@ -363,6 +364,18 @@ def test_low_4x4_transform_path_and_its_boundary(dev):
                         slot = 1 + (mb * 6 + k) % 63          # the one AC coefficient: every slot in turn
                     elif mode == "flat_then_busy":
                         slot = int(rng.integers(1, 4)) if mb < nmb // 2 else int(rng.integers(1, 64))
+                    elif mode == "three_then_four":
+                        # zig-zag slots inside the low 3x3 (the three-input transform), then, from the second
+                        # third of the picture on, slots on row 3 or column 3 of the low 4x4 as well (the
+                        # four-input one), then one block per macroblock group anywhere (the full one)
+                        in3 = (1, 2, 3, 4, 5, 7, 8, 12)
+                        edge4 = (6, 9, 11, 13, 17, 18, 24)
+                        if mb < nmb // 3:
+                            slot = in3[int(rng.integers(0, len(in3)))]
+                        elif mb < 2 * nmb // 3:
+                            slot = edge4[int(rng.integers(0, len(edge4)))] if rng.random() < 0.1 else in3[int(rng.integers(0, len(in3)))]
+                        else:
+                            slot = int(rng.integers(1, 64)) if (mb % 32 == 5 and k == 2) else in3[int(rng.integers(0, len(in3)))]
                     else:
                         slot = 0
                     val = int(rng.integers(-128, 64)) & 0xFF if slot else 0
