@@ -368,10 +368,10 @@ constexpr int kDecThreads = 64;
 #define MIRTJ_DEC_WAVES 1
 #endif
 #ifndef MIRTJ_DEC_ITERS
-#define MIRTJ_DEC_ITERS 3
+#define MIRTJ_DEC_ITERS 11
 #endif
 constexpr int kCoefStride = MIRTJ_COEF_STRIDE;  // int16 per lane: 64 + 8 pad (144 B, conflict-free b128 reads)
-constexpr int kDecIters = MIRTJ_DEC_ITERS;      // macroblock groups a wave works through, one after the other
+constexpr int kDecIters = MIRTJ_DEC_ITERS;      // macroblock groups a wave works through, one after the other (at most)
 constexpr int kSlotTabN = 64 + 16;              // slot table: 64 coefficient slots, then "block finished" entries
 constexpr int kMaxRawBytes = 15;                // the host refuses tables with more leading 8-bit coefficients
 #ifdef MIRTJ_TEST_GENERIC_PATHS  // test build: always take the paths real tables and whole packets rarely reach
@@ -379,6 +379,13 @@ constexpr bool kForceGenericPaths = true;
 #else
 constexpr bool kForceGenericPaths = false;
 #endif
+// waves per part of a picture with `groups` macroblock groups: a multiple of 8 (the XCD argument in k_decode)
+// that is not a multiple of 16
+__host__ __device__ constexpr uint32_t decode_slots(uint32_t groups) {
+  uint32_t s = ((groups + (uint32_t)kDecIters - 1u) / (uint32_t)kDecIters + 7u) & ~7u;
+  if (s == 0u) s = 8u;
+  return (s & 15u) == 0u ? s + 8u : s;
+}
 constexpr uint32_t kFetchSpan = 72;             // a block's loads stay below its start + this (64 + alignment + look-ahead)
 
 // ---------------------------------------------------------------------------------------
@@ -411,7 +418,9 @@ constexpr uint32_t kFetchSpan = 72;             // a block's loads stay below it
 //
 // A wave works through several groups so that it can request the next group's block offset before
 // parsing and the next group's stream bytes before transforming: only the first group pays the
-// three dependent loads (descriptor -> block offset -> stream bytes).
+// three dependent loads (descriptor -> block offset -> stream bytes).  Eleven groups per wave measured
+// 5 % faster than three at 1080p (A/B over 3..32, tools/ab_iters.sh); the number of waves per part
+// ("slots", decode_slots()) matters as well: 16 and 32 are consistently slow, 24 and 40 are not.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const FrameDev* __restrict__ frames,
                                                          const uint8_t* __restrict__ stream,
