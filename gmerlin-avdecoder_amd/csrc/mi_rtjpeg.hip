@@ -375,7 +375,7 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
     if ((rc = end(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
   }
   if ((rc = begin(MI_RTJ_K_DECODE)) != MI_RTJ_OK) return rc;
-  hipLaunchKernelGGL(k_decode, dim3(decode_slots(p->max_groups) * 3u, p->n), dim3(kDecThreads), 0, c->stream, p->d_frames, st, c->d_lut,
+  hipLaunchKernelGGL(k_decode, dim3(decode_slots(p->max_groups, (uint32_t)p->n) * 3u, p->n), dim3(kDecThreads), 0, c->stream, p->d_frames, st, c->d_lut,
                      p->d_blkoff, (uint8_t*)d_out);
   if ((rc = end(MI_RTJ_K_DECODE)) != MI_RTJ_OK) return rc;
   HIPCHK(c, hipGetLastError());

@@ -381,8 +381,14 @@ constexpr bool kForceGenericPaths = false;
 #endif
 // waves per part of a picture with `groups` macroblock groups: a multiple of 8 (the XCD argument in k_decode)
 // that is not a multiple of 16
-__host__ __device__ constexpr uint32_t decode_slots(uint32_t groups) {
-  uint32_t s = ((groups + (uint32_t)kDecIters - 1u) / (uint32_t)kDecIters + 7u) & ~7u;
+// and, for small batches, large enough that `frames` pictures still make kDecMinWaves waves (one packet: a
+// wave per group; a wave then works through fewer groups than kDecIters)
+constexpr uint32_t kDecMinWaves = 65536;
+__host__ __device__ constexpr uint32_t decode_slots(uint32_t groups, uint32_t frames) {
+  const uint32_t by_iters = (groups + (uint32_t)kDecIters - 1u) / (uint32_t)kDecIters;
+  uint32_t by_batch = (kDecMinWaves + 3u * frames - 1u) / (3u * (frames ? frames : 1u));
+  if (by_batch > groups) by_batch = groups;
+  uint32_t s = ((by_iters > by_batch ? by_iters : by_batch) + 7u) & ~7u;
   if (s == 0u) s = 8u;
   return (s & 15u) == 0u ? s + 8u : s;
 }
