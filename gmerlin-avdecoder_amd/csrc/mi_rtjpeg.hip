@@ -72,6 +72,7 @@ struct mi_rtj_plan {
   bool emit_walk = false;           // MI_RTJ_EMIT=walk: per-chunk re-walk instead of the length tables
   bool one_block_type = false;      // every frame's tables have lb8 == cb8: single-search summarize
   // speculative index (rtj_spec_kernels.h): one walker per kSpecChunk bytes, proven per packet afterwards
+  uint32_t dec_slots = 0;           // MI_RTJ_DEC_SLOTS (A/B): k_decode waves per part, 0 = decode_slots()
   int spec_mode = -1;               // MI_RTJ_SPEC: 0 never, 1 / 3 always with the short / long lead (no policy), 2 whatever the batch size, otherwise by batch size
   bool spec = false;
   uint64_t n_spec = 0, cap_spec = 0;       // walkers of this plan / allocated
@@ -375,7 +376,10 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
     if ((rc = end(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
   }
   if ((rc = begin(MI_RTJ_K_DECODE)) != MI_RTJ_OK) return rc;
-  hipLaunchKernelGGL(k_decode, dim3(decode_slots(p->max_groups, (uint32_t)p->n) * 3u, p->n), dim3(kDecThreads), 0, c->stream, p->d_frames, st, c->d_lut,
+  // the A/B override is honoured only where it still covers every group
+  const uint32_t dslots = p->dec_slots && p->dec_slots * (uint32_t)kDecIters >= p->max_groups ? p->dec_slots
+                                                                                              : decode_slots(p->max_groups, (uint32_t)p->n);
+  hipLaunchKernelGGL(k_decode, dim3(dslots * 3u, p->n), dim3(kDecThreads), 0, c->stream, p->d_frames, st, c->d_lut,
                      p->d_blkoff, (uint8_t*)d_out);
   if ((rc = end(MI_RTJ_K_DECODE)) != MI_RTJ_OK) return rc;
   HIPCHK(c, hipGetLastError());
@@ -568,6 +572,8 @@ mi_rtj_plan* mi_rtj_plan_create(mi_rtj_ctx* c, int n, const uint8_t* headers, co
     p->emit_walk = em && strcmp(em, "walk") == 0;
     const char* sp = getenv("MI_RTJ_SPEC");
     p->spec_mode = sp ? atoi(sp) : -1;
+    const char* ds = getenv("MI_RTJ_DEC_SLOTS");
+    p->dec_slots = ds ? (uint32_t)atoi(ds) : 0u;
   }
   if (hipSetDevice(c->device) != hipSuccess || plan_alloc_chunks(p) != MI_RTJ_OK) {
     mi_rtj_plan_destroy(p);

@@ -379,25 +379,25 @@ constexpr bool kForceGenericPaths = true;
 #else
 constexpr bool kForceGenericPaths = false;
 #endif
-// waves per part of a picture with `groups` macroblock groups: a multiple of 8 (the XCD argument in k_decode)
-// that is not a multiple of 16
-// and, for small batches, large enough that `frames` pictures still make kDecMinWaves waves (one packet: a
-// wave per group; a wave then works through fewer groups than kDecIters)
+// waves per part of a picture with `groups` macroblock groups: enough for kDecIters groups per wave and, for
+// small batches, enough that `frames` pictures still make kDecMinWaves waves (one packet: a wave per group; a
+// wave then works through fewer groups than kDecIters); always an ODD number.  Measured at 1080p x 4096
+// (tools/ab_slots.sh, profiles/r01/v19_waves_per_part_ab.txt): 25..45 odd 5.17-5.30 ms, 24 / 40 / 48 / 56
+// 5.42-5.72, 32 and 64 5.73-5.98.  With a multiple of 8 the three parts of a group share an XCD (workgroups
+// are dealt round-robin to the 8 XCDs) and their stream bytes come from HBM once; spreading them costs a few
+// per cent more HBM reads and is faster all the same.
 constexpr uint32_t kDecMinWaves = 65536;
 __host__ __device__ constexpr uint32_t decode_slots(uint32_t groups, uint32_t frames) {
   const uint32_t by_iters = (groups + (uint32_t)kDecIters - 1u) / (uint32_t)kDecIters;
   uint32_t by_batch = (kDecMinWaves + 3u * frames - 1u) / (3u * (frames ? frames : 1u));
   if (by_batch > groups) by_batch = groups;
-  uint32_t s = ((by_iters > by_batch ? by_iters : by_batch) + 7u) & ~7u;
-  if (s == 0u) s = 8u;
-  return (s & 15u) == 0u ? s + 8u : s;
+  return (by_iters > by_batch ? by_iters : by_batch) | 1u;
 }
 constexpr uint32_t kFetchSpan = 72;             // a block's loads stay below its start + this (64 + alignment + look-ahead)
 
 // ---------------------------------------------------------------------------------------
-// k_decode: grid (3 * slots, frames), one wave per workgroup; slots = groups / kDecIters rounded up
-// to a multiple of 8.  A group is kMbPerGroup consecutive macroblocks; a wave owns one PART of
-// kDecIters groups (slot, slot + slots, ...):
+// k_decode: grid (3 * slots, frames), one wave per workgroup; slots = decode_slots().  A group is
+// kMbPerGroup consecutive macroblocks; a wave owns one PART of up to kDecIters groups (slot, slot + slots, ...):
 //   part 0: the 64 upper luma blocks (Y0,Y1 of each MB), part 1: the 64 lower ones,
 //   part 2: 32 Cb + 32 Cr blocks.
 // Lanes of a wave hold horizontally adjacent blocks, so every row store of a wave covers 512
@@ -426,7 +426,7 @@ constexpr uint32_t kFetchSpan = 72;             // a block's loads stay below it
 // parsing and the next group's stream bytes before transforming: only the first group pays the
 // three dependent loads (descriptor -> block offset -> stream bytes).  Eleven groups per wave measured
 // 5 % faster than three at 1080p (A/B over 3..32, tools/ab_iters.sh); the number of waves per part
-// ("slots", decode_slots()) matters as well: 16 and 32 are consistently slow, 24 and 40 are not.
+// ("slots", decode_slots()) matters as well.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const FrameDev* __restrict__ frames,
                                                          const uint8_t* __restrict__ stream,
@@ -441,9 +441,7 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
   uint32_t* s_tab = s_lds + kCoefWords;  // per zig-zag slot: (dequantiser << 16) | scratch byte offset
 
   const FrameDev f = frames[blockIdx.y];
-  // part-major numbering with the slot count a multiple of 8: the three waves that share a set
-  // of groups get linear ids that differ by a multiple of 8, i.e. (as workgroups are dealt
-  // round-robin to the 8 XCDs) they share one L2 and the stream bytes come from HBM once
+  // part-major numbering (which XCD the three waves of a group land on: see decode_slots())
   const uint32_t slots = gridDim.x / 3u;
   const uint32_t part = blockIdx.x / slots, slot = blockIdx.x - part * slots;
   const uint32_t ngroups = (f.nmb + (uint32_t)kMbPerGroup - 1u) / (uint32_t)kMbPerGroup;
