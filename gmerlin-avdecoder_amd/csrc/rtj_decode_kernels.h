@@ -381,11 +381,14 @@ constexpr bool kForceGenericPaths = false;
 #endif
 // waves per part of a picture with `groups` macroblock groups: enough for kDecIters groups per wave and, for
 // small batches, enough that `frames` pictures still make kDecMinWaves waves (one packet: a wave per group; a
-// wave then works through fewer groups than kDecIters); always an ODD number.  Measured at 1080p x 4096
-// (tools/ab_slots.sh, profiles/r01/v19_waves_per_part_ab.txt): 25..45 odd 5.17-5.30 ms, 24 / 40 / 48 / 56
-// 5.42-5.72, 32 and 64 5.73-5.98.  With a multiple of 8 the three parts of a group share an XCD (workgroups
-// are dealt round-robin to the 8 XCDs) and their stream bytes come from HBM once; spreading them costs a few
-// per cent more HBM reads and is faster all the same.
+// wave then works through fewer groups than kDecIters).  Which XCD the three parts of a group run on matters
+// more than their number.  With part-major block numbering, measured at 1080p x 4096 (tools/ab_slots.sh,
+// profiles/r01/v19_waves_per_part_ab.txt): 25..45 odd 5.17-5.30 ms, 24 / 40 / 48 / 56 5.42-5.72, 32 and 64
+// 5.73-5.98 — with a multiple of 8 the three parts of a group share an XCD (workgroups are dealt round-robin to
+// the 8 XCDs) and their stream bytes and block offsets come from HBM once, and that is the SLOW arrangement;
+// spreading the parts over XCDs reads them three times (HBM traffic 1.17x -> 1.5x the algorithmic bytes) and is
+// 5 % faster all the same.  k_decode therefore numbers its blocks slot-major (5.23-5.25 ms whatever the count,
+// v19_block_numbering_ab.txt); the count is kept odd for good measure.
 constexpr uint32_t kDecMinWaves = 65536;
 __host__ __device__ constexpr uint32_t decode_slots(uint32_t groups, uint32_t frames) {
   const uint32_t by_iters = (groups + (uint32_t)kDecIters - 1u) / (uint32_t)kDecIters;
@@ -441,9 +444,10 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
   uint32_t* s_tab = s_lds + kCoefWords;  // per zig-zag slot: (dequantiser << 16) | scratch byte offset
 
   const FrameDev f = frames[blockIdx.y];
-  // part-major numbering (which XCD the three waves of a group land on: see decode_slots())
+  // slot-major numbering: the three parts of a slot are dispatched one after the other and (workgroups are
+  // dealt round-robin to the 8 XCDs) land on different XCDs — see decode_slots()
   const uint32_t slots = gridDim.x / 3u;
-  const uint32_t part = blockIdx.x / slots, slot = blockIdx.x - part * slots;
+  const uint32_t slot = blockIdx.x / 3u, part = blockIdx.x - slot * 3u;
   const uint32_t ngroups = (f.nmb + (uint32_t)kMbPerGroup - 1u) / (uint32_t)kMbPerGroup;
   if (slot >= ngroups) return;
   const int lane = threadIdx.x;
