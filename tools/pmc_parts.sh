@@ -1,5 +1,11 @@
 #!/bin/bash
-# PMC passes of k_decode with only the chroma / only the luma parts running (variants built by tools/ab_variants.sh)
+# PMC passes of k_decode with only the chroma / only the luma parts running.  The two libraries are built by
+# tools/ab_variants.sh with V=( [chroma]="-DMIRTJ_EXP_ONLY_PART=2" [luma]="-DMIRTJ_EXP_ONLY_PART=0" ) after adding,
+# behind k_decode's "if (slot >= ngroups) return;", the three lines
+#   #ifdef MIRTJ_EXP_ONLY_PART
+#     if ((MIRTJ_EXP_ONLY_PART == 2) != (part == 2u)) return;
+#   #endif
+# (not kept in the source: the pictures such a build makes are incomplete).  Result: profiles/r01/v20_pmc_luma_vs_chroma.json
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_parts
