@@ -242,6 +242,9 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
     uint32_t cur[33];
 #pragma unroll
     for (int k = 0; k < 33; k++) cur[k] = buf[k];
+    // the records of the tile before leave now, BEFORE the next tile's loads are queued: loads and stores
+    // complete in order, so a store queued after those loads would have to be waited for with them (-3 %)
+    flush(8);
     if (t + 1 < kSpan / kSpecTile) request(t + 1);  // in flight while this tile is parsed
 #pragma unroll
     for (int i = 0; i < kSpecTile / 16; i++) {
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
           }
         }
       }
-      flush(8);  // at most 7 + 16 records are staged at this point
+      flush(16);  // inside a tile only when the ring is half full: at most 15 + 16 records are staged at this point
     }
   }
   flush(1);  // the last, partial group (the slots past cnt are never read)
