@@ -505,21 +505,41 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
     return b;
   };
 
+  // Vector-memory operations of a wave complete in issue order, loads and stores alike (one counter, vmcnt), so a
+  // load issued behind the eight row stores of a group is only known to be complete once those stores are.  The
+  // loop is therefore ordered so that nothing it waits for is younger than a store: a group's stream bytes AND the
+  // block offset of the group after it are requested before the group in hand is transformed, and waited for
+  // right behind its row stores with a counted wait, "all but the 8 youngest" (arrived_behind_stores below) — by
+  // then they have had the whole transform to arrive.  The compiler cannot be made to place that wait: wherever
+  // control flow joins it assumes the path with the fewest operations in flight and emits vmcnt(0) or vmcnt(1),
+  // i.e. a wait for the stores.  These loads are therefore issued from inline assembly (the compiler does not know
+  // they are pending) and waited for by hand; `next_bytes` and `pos_nn` must not be read before that wait.
+  // (Round 1 loaded the offset at the top of the next iteration and the compiler waited with vmcnt(0) at the loop
+  // end: every wave sat out the latency of its row stores once per group.)
   uint32_t grp = slot;
   uint32_t mb = grp * (uint32_t)kMbPerGroup + dmb;
   bool valid = mb < f.nmb;
-  uint32_t pos0 = valid ? off[6u * mb + kblk] : 0u;  // block start relative to the first data byte
+  uint32_t pos0 = off[valid ? 6u * mb + kblk : 0u];  // block start relative to the first data byte
+  uint32_t pos_n;                                    // the same for the wave's next group
+  {
+    const uint32_t mb_n = (grp + slots) * (uint32_t)kMbPerGroup + dmb;
+    pos_n = off[mb_n < f.nmb ? 6u * mb_n + kblk : 0u];
+  }
+  pos0 = valid ? pos0 : 0u;
   bool inside = !kForceGenericPaths && __all(pos0 + kFetchSpan <= f.data_len);  // wave-uniform
   Bytes cur = fetch(pos0, inside, 9);  // 32 bytes (+ alignment): all of most blocks
   bool try_lo = true;  // wave-uniform: test this wave's blocks for "low 4x4 only" until a test fails
+  // the first group's loads are waited for here, not inside the loop: a wait at the top of the loop would be a
+  // wait for everything in flight (it could not tell the first entry from the back edge), the row stores included
+  asm volatile("" ::"v"(cur.d[0]), "v"(cur.d[1]), "v"(cur.d[2]), "v"(cur.d[3]), "v"(cur.d[4]), "v"(cur.d[5]),
+               "v"(cur.d[6]), "v"(cur.d[7]), "v"(cur.d[8]), "v"(pos_n));
 
   for (int it = 0; it < kDecIters; it++) {
-    // ---- request the next group's block offset before anything else ----
     const uint32_t grp_n = grp + slots;
     const bool have_n = it + 1 < kDecIters && grp_n < ngroups;  // wave-uniform
     const uint32_t mb_n = grp_n * (uint32_t)kMbPerGroup + dmb;
     const bool valid_n = have_n && mb_n < f.nmb;
-    const uint32_t pos_n = valid_n ? off[6u * mb_n + kblk] : 0u;
+    pos_n = valid_n ? pos_n : 0u;
 
     const uint32_t sh = (uint32_t)((uintptr_t)(data + pos0) & 3u);
     uint32_t d0 = cur.d[0], d1 = cur.d[1], d2 = cur.d[2], d3 = cur.d[3], d4 = cur.d[4];
@@ -613,12 +633,33 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
       }
     }
 
-    // ---- request the next group's stream bytes: they arrive while this group is transformed ----
-    Bytes nxt;
+    // ---- request the next group's stream bytes and the block offset of the group after it: they arrive while
+    // this group is transformed ----
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t nb0, nb1;
+    uint32_t nb2, pos_nn;
+    Bytes near_end;  // the next group's bytes when they were fetched with masks (end of the packet)
     bool inside_n = false;
     if (have_n) {
       inside_n = !kForceGenericPaths && __all(pos_n + kFetchSpan <= f.data_len);
-      nxt = fetch(pos_n, inside_n, 9);
+      const uint32_t mb_nn = (grp_n + slots) * (uint32_t)kMbPerGroup + dmb;
+      const uint32_t* offp = off + (it + 2 < kDecIters && mb_nn < f.nmb ? 6u * mb_nn + kblk : 0u);
+      const uint8_t* g = data + pos_n;
+      const uint32_t* g4 = (const uint32_t*)(g - ((uintptr_t)g & 3u));
+      if (!inside_n) {  // near the packet's end: masked loads, waited for at once (rare); the hand-issued loads
+        near_end = fetch(pos_n, false, 9);  // below then read this packet's descriptor (64 valid bytes) instead
+        g4 = (const uint32_t*)(frames + blockIdx.y);
+      }
+      // one block, issued on every path that has a next group: its results take part in no selection before the
+      // wait (a selection could be a register copy, and a copy of a register that is still being filled is wrong)
+      asm volatile(
+          "global_load_dwordx4 %0, %4, off\n\t"
+          "global_load_dwordx4 %1, %4, off offset:16\n\t"
+          "global_load_dword %2, %4, off offset:32\n\t"
+          "global_load_dword %3, %5, off"
+          : "=&v"(nb0), "=&v"(nb1), "=&v"(nb2), "=&v"(pos_nn)
+          : "v"(g4), "v"(offp)
+          : "memory");
     }
 
     // ---- does any block of the wave reach outside the low 4x4?  (columns 4-7, rows 4-7) ----
@@ -754,11 +795,35 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
       }
     }
     if (!have_n) break;
+    // Every transform variant ends with eight row stores, so behind the join "all but the 8 youngest operations"
+    // is exactly "everything requested before the transform" — unless no lane had a live block: such a wave
+    // stored nothing and waits for all there is.
+    {
+      const unsigned long long any_live = __ballot(live_blk);
+      asm volatile(
+          "s_cmp_eq_u64 %4, 0\n\t"
+          "s_cbranch_scc1 .Lmirtj_nolive_%=\n\t"
+          "s_waitcnt vmcnt(8)\n\t"
+          "s_branch .Lmirtj_arrived_%=\n"
+          ".Lmirtj_nolive_%=:\n\t"
+          "s_waitcnt vmcnt(0)\n"
+          ".Lmirtj_arrived_%=:"
+          : "+v"(nb0), "+v"(nb1), "+v"(nb2), "+v"(pos_nn)
+          : "s"(any_live)
+          : "scc", "memory");
+    }
     grp = grp_n;
     mb = mb_n;
     valid = valid_n;
     pos0 = pos_n;
-    cur = nxt;
+    pos_n = pos_nn;
+    if (inside_n) {
+      cur.d[0] = nb0.x; cur.d[1] = nb0.y; cur.d[2] = nb0.z; cur.d[3] = nb0.w;
+      cur.d[4] = nb1.x; cur.d[5] = nb1.y; cur.d[6] = nb1.z; cur.d[7] = nb1.w;
+      cur.d[8] = nb2;
+    } else {
+      cur = near_end;
+    }
     inside = inside_n;
   }
 }

@@ -46,3 +46,25 @@ def test_product_does_not_link_or_import_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", ".c")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "rtj_oracle" not in txt and "rtjlib" not in txt and "oracle/" not in txt, f
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd") or not os.path.exists("/opt/rocm/bin/hipcc"),
+                    reason="compiler check; run where the library is cross-compiled")
+def test_hand_issued_loads_of_k_decode_are_not_touched_before_their_wait(tmp_path):
+    """k_decode issues its look-ahead loads from inline assembly and waits for them by hand (a counted
+    vmcnt behind the row stores); the compiler does not know those registers are still being filled.
+    tools/check_async_loads.py reads the device assembly of the shipped sources and fails if anything
+    touches them early, if a compiler-placed vmcnt wait sits in between, or if a transform variant does
+    not issue exactly the eight stores the counted wait assumes."""
+    import subprocess
+    import sys
+    csrc = os.path.join(ROOT, "gmerlin-avdecoder_amd", "csrc")
+    out = tmp_path / "lib.so"
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                    "-Wno-unused-function", "-save-temps=obj", "-o", str(out), os.path.join(csrc, "mi_rtjpeg.hip")],
+                   check=True, capture_output=True, cwd=str(tmp_path))
+    asm = tmp_path / "mi_rtjpeg-hip-amdgcn-amd-amdhsa-gfx950.s"
+    assert asm.exists()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_async_loads.py"), str(asm)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

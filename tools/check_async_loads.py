@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Checks the compiled k_decode for the one thing the compiler does not know (csrc/rtj_decode_kernels.h): the
+registers that the hand-issued loads of the group loop are filling must not be touched between the loads and the
+hand-placed `s_waitcnt vmcnt(8)` / `vmcnt(0)` block behind the row stores, every transform variant on the way must
+hold exactly eight stores, and no other vector-memory instruction or compiler-placed vmcnt wait may sit in between.
+
+    python tools/check_async_loads.py file.s        (hipcc -save-temps device assembly)
+
+Exit status 0 = clean.  Run by tests/test_abi_cpu.py on the cross-compiled kernel."""
+import re
+import sys
+
+
+def regs_of(tok):
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.fullmatch(r"v(\d+)", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def all_vregs(line):
+    out = set()
+    for tok in re.findall(r"v\[\d+:\d+\]|v\d+", line):
+        out |= regs_of(tok)
+    return out
+
+
+def check(path, kernel="k_decode"):
+    lines = open(path).read().split("\n")
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN5mirtj\d+" + kernel + r"E", l) and l.rstrip().endswith(("Ph", ":")) or
+                 (re.match(r"^_ZN5mirtj\d+" + kernel + r"E.*:", l)))
+    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
+    body = lines[start:end]
+    # the hand-issued block: an ASMSTART region that holds global_load_dwordx4 (there is exactly one such region
+    # inside the group loop)
+    blocks = []
+    i = 0
+    while i < len(body):
+        if "#ASMSTART" in body[i]:
+            j = i
+            while "#ASMEND" not in body[j]:
+                j += 1
+            txt = body[i:j]
+            if any("global_load_dwordx4" in t for t in txt):
+                blocks.append((i, j))
+            i = j
+        i += 1
+    if len(blocks) != 1:
+        return [f"expected one hand-issued load block, found {len(blocks)}"]
+    b0, b1 = blocks[0]
+    pending = set()
+    for t in body[b0:b1]:
+        t = t.strip()
+        if t.startswith("global_load"):
+            pending |= regs_of(t.split()[1].rstrip(","))
+    errs = []
+    # scan forward from the loads to the hand-placed wait block (s_waitcnt vmcnt(8) inside an ASMSTART region)
+    waited = False
+    stores_by_path = []
+    stores = 0
+    for k in range(b1 + 1, len(body)):
+        raw = body[k]
+        t = raw.split(";")[0].strip()
+        if "#ASMSTART" in raw:
+            j = k
+            while "#ASMEND" not in body[j]:
+                j += 1
+            if any("s_waitcnt vmcnt(8)" in x for x in body[k:j]):
+                if not any("s_waitcnt vmcnt(0)" in x for x in body[k:j]):
+                    errs.append(f"line {k}: the wait block has no vmcnt(0) arm for waves that stored nothing")
+                waited = True
+                break
+        if not t or t.endswith(":") or t.startswith("."):
+            if t.endswith(":") and stores:
+                stores_by_path.append(stores)
+                stores = 0
+            continue
+        op = t.split()[0]
+        if op == "s_waitcnt" and "vmcnt" in t:
+            errs.append(f"line {k}: compiler-placed '{t}' while hand-issued loads are pending")
+            continue
+        if op.startswith("global_store"):
+            stores += 1
+            continue
+        if op.startswith(("global_load", "buffer_", "flat_", "global_atomic")):
+            errs.append(f"line {k}: vector-memory instruction '{t}' between the loads and their wait")
+        if op == "s_endpgm":
+            break
+        touched = all_vregs(t) & pending
+        if touched:
+            errs.append(f"line {k}: '{t}' touches pending v{sorted(touched)}")
+    if stores:
+        stores_by_path.append(stores)
+    if not waited:
+        errs.append("hand-placed wait block not found behind the loads")
+    if any(n != 8 for n in stores_by_path) or not stores_by_path:
+        errs.append(f"row stores per transform variant: {stores_by_path} (the counted wait assumes 8 on every path)")
+    return errs
+
+
+if __name__ == "__main__":
+    e = check(sys.argv[1])
+    for x in e:
+        print("ASYNC-LOAD CHECK:", x)
+    print("pending-load check:", "clean" if not e else f"{len(e)} problem(s)")
+    sys.exit(1 if e else 0)
