@@ -50,12 +50,12 @@ TEST_VARIANT = os.path.join(LIBDIR, "libmi_rtjpeg_generic_paths.so")
 def build_test_variant(force=False):
     """The same library compiled with -DMIRTJ_TEST_GENERIC_PATHS: the kernels always take the paths
     that real tables and whole packets rarely reach (run-time raw-byte count in the parse loop, masked
-    loads near a packet's end).  Loaded only by tests/test_gpu_variant_paths.py."""
+    loads near a packet's end; a single DC-only block is enough for a group to put its other blocks off).  Loaded only by tests/test_gpu_variant_paths.py."""
     if not force and os.path.exists(TEST_VARIANT) and \
             all(os.path.getmtime(f) <= os.path.getmtime(TEST_VARIANT) for f in _deps()):
         return TEST_VARIANT
     old = os.environ.get("MI_RTJ_CFLAGS")
-    os.environ["MI_RTJ_CFLAGS"] = ((old + " ") if old else "") + "-DMIRTJ_TEST_GENERIC_PATHS"
+    os.environ["MI_RTJ_CFLAGS"] = ((old + " ") if old else "") + "-DMIRTJ_TEST_GENERIC_PATHS -DMIRTJ_DC_DEFER=1"
     try:
         return build(force=True, out=TEST_VARIANT)
     finally:

@@ -25,6 +25,8 @@ using namespace mirtj;
 namespace {
 
 constexpr size_t kAllocPad = 256;  // kernels may read a few bytes past a packet's last dword
+constexpr uint64_t kDeferMinGroups = 4096;  // plans with fewer macroblock groups never put blocks off
+constexpr int kMaxPlanFrames = 65535;       // a plan's frames are the y dimension of every grid
 
 std::mutex g_err_mu;
 std::string g_create_err = "";
@@ -90,6 +92,9 @@ struct mi_rtj_plan {
   uint32_t* d_spec_todo = nullptr;         // [n + 1]: count, then the packets left to the exact kernels
   int cap_spec_frames = 0;
   uint32_t* d_spec_state = nullptr;        // [2]: launches in a row that refused every packet, launches left paused
+  unsigned long long* d_defer = nullptr;   // [k_decode waves][kDecIters]: lanes whose blocks k_decode put off
+  size_t cap_defer = 0, defer_words = 0;   // allocated / used by the last launch
+  bool defer_on = true;                    // MI_RTJ_DEFER=0 switches the putting-off off (A/B)
   std::vector<Timed> ev[MI_RTJ_NUM_KERNELS];  // one pair per launch while profiling
   int launches = 0;
 };
@@ -155,6 +160,8 @@ int fill_frame(mi_rtj_ctx* c, const uint8_t* hdr, uint64_t pkt_off, uint32_t pkt
   f->blk_base = blk_base;
   f->mbw = (uint32_t)w / 16;
   f->nmb = f->mbw * ((uint32_t)h / 16);
+  if ((uint64_t)f->nmb * 6 * 64 + kAllocPad >= 0xFFFFFFFFull)  // block offsets and the walkers' positions are 32-bit
+    return fail(c, MI_RTJ_ERR_GEOMETRY, "picture of %dx%d: its worst-case stream does not fit 32-bit offsets", w, h);
   f->nchunks = (f->data_len + kChunk - 1) / kChunk;
   if (f->nchunks == 0) f->nchunks = 1;
   return MI_RTJ_OK;
@@ -181,6 +188,7 @@ int plan_alloc_chunks(mi_rtj_plan* p) {
       (void)hipFree(p->d_lentab);
       p->d_summary = nullptr;
       p->d_lentab = nullptr;
+      p->n_chunks = 0;
     }
     HIPCHK(c, hipMalloc((void**)&p->d_summary, sizeof(uint32_t) * kEntries * chunks));
     HIPCHK(c, hipMalloc((void**)&p->d_lentab, sizeof(uint16_t) * kChunk * chunks + 64));
@@ -192,6 +200,7 @@ int plan_alloc_chunks(mi_rtj_plan* p) {
       (void)hipFree(p->d_chunk_pos);
       (void)hipFree(p->d_chunk_mb);
       p->d_chunk_pos = p->d_chunk_mb = nullptr;
+      p->n_chunk_entries = 0;
     }
     HIPCHK(c, hipMalloc((void**)&p->d_chunk_pos, sizeof(uint32_t) * entries));
     HIPCHK(c, hipMalloc((void**)&p->d_chunk_mb, sizeof(uint32_t) * entries));
@@ -225,6 +234,10 @@ int plan_alloc_chunks(mi_rtj_plan* p) {
         (void)hipFree(p->d_spec_hand);
         (void)hipFree(p->d_spec_fix);
         p->d_spec_chunks = nullptr;
+        p->d_spec_rec = nullptr;
+        p->d_spec_nrec = p->d_spec_wstart = nullptr;
+        p->d_spec_hand = p->d_spec_fix = nullptr;
+        p->cap_spec = 0;  // a failed hipMalloc below must not leave freed pointers behind
       }
       HIPCHK(c, hipMalloc((void**)&p->d_spec_chunks, sizeof(SpecChunkDev) * p->n_spec));
       HIPCHK(c, hipMalloc((void**)&p->d_spec_rec, sizeof(uint16_t) * kSpecCap * (p->n_spec + 1)));  // + a spare row for idle lanes
@@ -244,6 +257,8 @@ int plan_alloc_chunks(mi_rtj_plan* p) {
         (void)hipFree(p->d_spec_base);
         (void)hipFree(p->d_spec_ok);
         (void)hipFree(p->d_spec_todo);
+        p->d_spec_base = p->d_spec_ok = p->d_spec_todo = nullptr;
+        p->cap_spec_frames = 0;
       }
       HIPCHK(c, hipMalloc((void**)&p->d_spec_base, sizeof(uint32_t) * (p->h_frames.size() + 1)));
       HIPCHK(c, hipMalloc((void**)&p->d_spec_ok, sizeof(uint32_t) * p->h_frames.size()));
@@ -379,8 +394,30 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
   // the A/B override is honoured only where it still covers every group
   const uint32_t dslots = p->dec_slots && p->dec_slots * (uint32_t)kDecIters >= p->max_groups ? p->dec_slots
                                                                                               : decode_slots(p->max_groups, (uint32_t)p->n);
+  // groups with many DC-only blocks fill those in and put their other blocks off (one lane mask per wave and
+  // iteration, zeroed here); k_decode_list takes the blocks put off, 64 per round.  MI_RTJ_DEFER=0: never put off.
+  unsigned long long* defer = nullptr;
+  if (p->defer_on) {
+    const size_t words = (size_t)dslots * 3u * (size_t)p->n * (size_t)kDecIters;
+    if (words > p->cap_defer) {
+      if (p->d_defer) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(p->d_defer);
+        p->d_defer = nullptr;
+        p->cap_defer = 0;
+      }
+      HIPCHK(c, hipMalloc((void**)&p->d_defer, words * sizeof(unsigned long long)));
+      p->cap_defer = words;
+    }
+    defer = p->d_defer;
+    p->defer_words = words;
+    HIPCHK(c, hipMemsetAsync(defer, 0, words * sizeof(unsigned long long), c->stream));
+  }
   hipLaunchKernelGGL(k_decode, dim3(dslots * 3u, p->n), dim3(kDecThreads), 0, c->stream, p->d_frames, st, c->d_lut,
-                     p->d_blkoff, (uint8_t*)d_out);
+                     p->d_blkoff, (uint8_t*)d_out, defer);
+  if (defer)
+    hipLaunchKernelGGL(k_decode_list, dim3(dslots * 3u, p->n), dim3(kDecThreads), 0, c->stream, p->d_frames, st, c->d_lut,
+                       p->d_blkoff, (uint8_t*)d_out, defer);
   if ((rc = end(MI_RTJ_K_DECODE)) != MI_RTJ_OK) return rc;
   HIPCHK(c, hipGetLastError());
   p->launches++;
@@ -539,6 +576,10 @@ mi_rtj_plan* mi_rtj_plan_create(mi_rtj_ctx* c, int n, const uint8_t* headers, co
     fail(c, MI_RTJ_ERR_ARG, "mi_rtj_plan_create: bad argument");
     return nullptr;
   }
+  if (n > kMaxPlanFrames) {
+    fail(c, MI_RTJ_ERR_ARG, "mi_rtj_plan_create: %d packets; a plan takes at most %d (split the batch)", n, kMaxPlanFrames);
+    return nullptr;
+  }
   mi_rtj_plan* p = new mi_rtj_plan();
   p->ctx = c;
   p->n = n;
@@ -574,6 +615,9 @@ mi_rtj_plan* mi_rtj_plan_create(mi_rtj_ctx* c, int n, const uint8_t* headers, co
     p->spec_mode = sp ? atoi(sp) : -1;
     const char* ds = getenv("MI_RTJ_DEC_SLOTS");
     p->dec_slots = ds ? (uint32_t)atoi(ds) : 0u;
+    // putting blocks off costs a memset and a second launch: batches only (the one-packet plan never does)
+    const char* df = getenv("MI_RTJ_DEFER");
+    p->defer_on = df ? atoi(df) != 0 : (uint64_t)p->n * p->max_groups >= kDeferMinGroups;
   }
   if (hipSetDevice(c->device) != hipSuccess || plan_alloc_chunks(p) != MI_RTJ_OK) {
     mi_rtj_plan_destroy(p);
@@ -614,6 +658,7 @@ void mi_rtj_plan_destroy(mi_rtj_plan* p) {
   if (p->d_spec_todo) (void)hipFree(p->d_spec_todo);
   if (p->d_spec_state) (void)hipFree(p->d_spec_state);
   if (p->d_spec_ok) (void)hipFree(p->d_spec_ok);
+  if (p->d_defer) (void)hipFree(p->d_defer);
   delete p;
 }
 
@@ -690,6 +735,35 @@ int mi_rtj_plan_spec_stats(mi_rtj_plan* p, int* proven, long long* walkers, long
   return MI_RTJ_OK;
 }
 
+int mi_rtj_plan_deferred(mi_rtj_plan* p, long long* blocks) {
+  if (!p || !blocks) return MI_RTJ_ERR_ARG;
+  mi_rtj_ctx* c = p->ctx;
+  *blocks = 0;
+  if (!p->d_defer || !p->defer_words) return MI_RTJ_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  unsigned long long* d_sum = nullptr;
+  HIPCHK(c, hipMalloc((void**)&d_sum, sizeof(unsigned long long)));
+  HIPCHK(c, hipMemsetAsync(d_sum, 0, sizeof(unsigned long long), c->stream));
+  hipLaunchKernelGGL(k_count_bits, dim3(256), dim3(256), 0, c->stream, p->d_defer, p->defer_words, d_sum);
+  unsigned long long sum = 0;
+  HIPCHK(c, hipMemcpyAsync(&sum, d_sum, sizeof(sum), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(d_sum);
+  *blocks = (long long)sum;
+  return MI_RTJ_OK;
+}
+
+#ifdef MIRTJ_STAMPS
+// diagnostic builds only (not declared in include/mi_rtjpeg.h): cycles per k_decode section since the last call
+extern "C" int mi_rtj_debug_stamps(unsigned long long out[8]) {
+  if (hipDeviceSynchronize() != hipSuccess) return MI_RTJ_ERR_HIP;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return MI_RTJ_ERR_HIP;
+  unsigned long long zero[8] = {};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zero, sizeof zero) != hipSuccess) return MI_RTJ_ERR_HIP;
+  return MI_RTJ_OK;
+}
+#endif
+
 int mi_rtj_plan_read_index(mi_rtj_plan* p, uint32_t* dst, size_t max_entries) {
   if (!p || !dst) return MI_RTJ_ERR_ARG;
   mi_rtj_ctx* c = p->ctx;
@@ -720,6 +794,7 @@ int decode_one_launch(mi_rtj_ctx* c, const uint8_t* pkt, size_t len) {
     c->single = new mi_rtj_plan();
     c->single->ctx = c;
     c->single->n = 1;
+    c->single->defer_on = false;  // one packet: a second launch costs more than idle lanes
     c->single->h_frames.resize(1);
   }
   mi_rtj_plan* p = c->single;

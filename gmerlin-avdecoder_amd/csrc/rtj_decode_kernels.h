@@ -431,16 +431,38 @@ constexpr uint32_t kFetchSpan = 72;             // a block's loads stay below it
 // 5 % faster than three at 1080p (A/B over 3..32, tools/ab_iters.sh); the number of waves per part
 // ("slots", decode_slots()) matters as well.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const FrameDev* __restrict__ frames,
-                                                         const uint8_t* __restrict__ stream,
-                                                         const QTab* __restrict__ lut,
-                                                         const uint32_t* __restrict__ blkoff,
-                                                         uint8_t* __restrict__ outbuf) {
-  constexpr int kCoefWords = kDecThreads * kCoefStride / 2;
+#ifndef MIRTJ_DC_DEFER
+#define MIRTJ_DC_DEFER 16
+#endif
+constexpr uint32_t kDcDeferMin = MIRTJ_DC_DEFER;  // "DC only" blocks a group must hold before its other blocks are put off
+constexpr int kCoefWords = kDecThreads * kCoefStride / 2;
 #ifndef MIRTJ_DEC_LDS_PAD
 #define MIRTJ_DEC_LDS_PAD 0
 #endif
-  __shared__ __attribute__((aligned(16))) uint32_t s_lds[kCoefWords + kSlotTabN + MIRTJ_DEC_LDS_PAD];
+constexpr int kDecLdsWords = kCoefWords + kSlotTabN + MIRTJ_DEC_LDS_PAD;
+constexpr int kDecListWords = kDecIters * 64 / 2;  // k_decode_list: one 16-bit (iteration, lane) code per block put off
+
+#ifdef MIRTJ_STAMPS  // diagnostic build: where a wave's time goes (shader cycles per section, summed over all waves)
+__device__ unsigned long long g_stamps[8];
+#define MIRTJ_STAMP(i)                                              \
+  do {                                                              \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();     \
+    st_acc[i] += t_ - st_last;                                      \
+    st_last = t_;                                                   \
+  } while (0)
+#else
+#define MIRTJ_STAMP(i) \
+  do {                 \
+  } while (0)
+#endif
+
+// kList == false: k_decode proper.  kList == true: k_decode_list, the same wave over the blocks its k_decode
+// twin put off (`defer`, one 64-bit lane mask per wave and iteration), taken 64 at a time.
+template <bool kList>
+__device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const FrameDev* __restrict__ frames,
+                                            const uint8_t* __restrict__ stream, const QTab* __restrict__ lut,
+                                            const uint32_t* __restrict__ blkoff, uint8_t* __restrict__ outbuf,
+                                            unsigned long long* __restrict__ defer) {
   uint32_t* s_tab = s_lds + kCoefWords;  // per zig-zag slot: (dequantiser << 16) | scratch byte offset
 
   const FrameDev f = frames[blockIdx.y];
@@ -450,6 +472,9 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
   const uint32_t slot = blockIdx.x / 3u, part = blockIdx.x - slot * 3u;
   const uint32_t ngroups = (f.nmb + (uint32_t)kMbPerGroup - 1u) / (uint32_t)kMbPerGroup;
   if (slot >= ngroups) return;
+#ifdef MIRTJ_EXP_ONLY_PART  // experiment builds (tools/pmc_parts.sh): 2 = only the chroma part works, 0 = only the luma parts
+  if ((MIRTJ_EXP_ONLY_PART == 2) != (part == 2u)) return;
+#endif
   const int lane = threadIdx.x;
   const uint32_t* off = blkoff + f.blk_base;
   const QTab& qt = lut[f.qidx];
@@ -468,10 +493,78 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
   const int k63 = 63;
   const uint4* my = (const uint4*)((const uint8_t*)s_lds + (size_t)lane * (kCoefStride * 2));
 
-  // ---- which block of a group is mine ----
-  const uint32_t dmb = chroma ? (uint32_t)(lane & 31) : (uint32_t)(lane >> 1);
-  const uint32_t kblk = chroma ? 4u + (uint32_t)(lane >> 5) : 2u * part + (uint32_t)(lane & 1);
+  // ---- which block of a group is mine (k_decode; k_decode_list looks both up per round) ----
+  const uint32_t dmb_own = chroma ? (uint32_t)(lane & 31) : (uint32_t)(lane >> 1);
+  const uint32_t kblk_own = chroma ? 4u + (uint32_t)(lane >> 5) : 2u * part + (uint32_t)(lane & 1);
   const uint8_t* data = stream + f.data_off;
+  unsigned long long* my_defer =
+      defer ? defer + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)kDecIters : nullptr;
+
+  // ---- k_decode_list: the blocks put off, in order, as (iteration << 6 | lane) codes in LDS ----
+  uint32_t n_listed = 0;
+  uint16_t* s_list = (uint16_t*)(s_lds + kDecLdsWords);
+  if (kList) {
+    unsigned long long mine = lane < kDecIters ? my_defer[lane] : 0ull;
+    uint32_t before = 0;
+#pragma unroll
+    for (int i = 0; i < kDecIters; i++) {
+      const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(mine >> 32), i) << 32) |
+                                   (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, i);  // wave-uniform
+      if (m >> lane & 1ull) {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        s_list[before + rank] = (uint16_t)((uint32_t)i << 6 | (uint32_t)lane);
+      }
+      before += (uint32_t)__builtin_popcountll(m);
+    }
+    n_listed = before;
+    if (n_listed == 0u) return;
+    __syncthreads();
+  }
+  // iteration `it` of this wave: which group, which block of it, and is there one (per lane)
+  struct Src {
+    uint32_t grp, dmb, kblk, mb;
+    bool valid;
+  };
+  auto source = [&](uint32_t it) -> Src {
+    Src r;
+    if (!kList) {
+      r.grp = slot + it * slots;
+      r.dmb = dmb_own;
+      r.kblk = kblk_own;
+      r.mb = r.grp * (uint32_t)kMbPerGroup + r.dmb;
+      r.valid = it < (uint32_t)kDecIters && r.mb < f.nmb;
+    } else {
+      const uint32_t e = it * 64u + (uint32_t)lane;
+      r.valid = e < n_listed;
+      const uint32_t code = r.valid ? (uint32_t)s_list[e] : 0u;
+      const uint32_t ls = code & 63u;
+      r.grp = slot + (code >> 6) * slots;
+      r.dmb = chroma ? ls & 31u : ls >> 1;
+      r.kblk = chroma ? 4u + (ls >> 5) : 2u * part + (ls & 1u);
+      r.mb = r.grp * (uint32_t)kMbPerGroup + r.dmb;
+    }
+    return r;
+  };
+  auto more_after = [&](uint32_t it) -> bool {  // wave-uniform: is there an iteration it + 1
+    return kList ? (it + 1u) * 64u < n_listed : it + 1u < (uint32_t)kDecIters && slot + (it + 1u) * slots < ngroups;
+  };
+
+  // ---- "DC only" blocks as the encoder writes them: DC, bt8 zero bytes, then one run over the other 63 - bt8 slots
+  // (RTjpeg_b2s, lib/RTjpeg.c:109-155: a run is the byte 63 + length).  Such a block is the pixel
+  // clamp((int16(DC * q0) + 4) >> 3) 64 times over: every term of both passes but the DC path is zero
+  // (lib/RTjpeg.c:2223-2238 is the reference's own shortcut for it).  The test reads the block's first 16 bytes.
+  const bool dc_test = !kList && my_defer != nullptr && bt8 <= 14u;
+  unsigned long long dcm_lo = 0, dcm_hi = 0, dcp_lo = 0, dcp_hi = 0;  // byte masks / expected bytes, wave-uniform
+  {
+    const uint32_t nb1 = bt8 + 2u;  // bytes 0 .. bt8+1 take part (byte 0, DC, is masked out again)
+    dcm_lo = nb1 >= 8u ? ~0ull : (1ull << (8u * nb1)) - 1ull;
+    dcm_hi = nb1 > 8u ? (nb1 >= 16u ? ~0ull : (1ull << (8u * (nb1 - 8u))) - 1ull) : 0ull;
+    dcm_lo &= ~0xFFull;
+    const unsigned long long run = 126ull - bt8;
+    if (bt8 + 1u < 8u) dcp_lo = run << (8u * (bt8 + 1u));
+    else dcp_hi = run << (8u * (bt8 + 1u - 8u));
+  }
+  const int q_dc = chroma ? qt.ciqt[0] : qt.liqt[0];
 
   // the dword that holds stream byte `p` and the four after it, bytes at or past data_len read as 0;
   // `inside`: every lane's loads are known to lie inside the packet
@@ -516,16 +609,13 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
   // they are pending) and waited for by hand; `next_bytes` and `pos_nn` must not be read before that wait.
   // (Round 1 loaded the offset at the top of the next iteration and the compiler waited with vmcnt(0) at the loop
   // end: every wave sat out the latency of its row stores once per group.)
-  uint32_t grp = slot;
-  uint32_t mb = grp * (uint32_t)kMbPerGroup + dmb;
-  bool valid = mb < f.nmb;
-  uint32_t pos0 = off[valid ? 6u * mb + kblk : 0u];  // block start relative to the first data byte
-  uint32_t pos_n;                                    // the same for the wave's next group
-  {
-    const uint32_t mb_n = (grp + slots) * (uint32_t)kMbPerGroup + dmb;
-    pos_n = off[mb_n < f.nmb ? 6u * mb_n + kblk : 0u];
-  }
-  pos0 = valid ? pos0 : 0u;
+#ifdef MIRTJ_STAMPS
+  unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+#endif
+  Src s0 = source(0u), s1 = source(1u);
+  uint32_t pos0 = off[s0.valid ? 6u * s0.mb + s0.kblk : 0u];  // block start relative to the first data byte
+  uint32_t pos_n = off[s1.valid ? 6u * s1.mb + s1.kblk : 0u];  // the same for the wave's next iteration
+  pos0 = s0.valid ? pos0 : 0u;
   bool inside = !kForceGenericPaths && __all(pos0 + kFetchSpan <= f.data_len);  // wave-uniform
   Bytes cur = fetch(pos0, inside, 9);  // 32 bytes (+ alignment): all of most blocks
   bool try_lo = true;  // wave-uniform: test this wave's blocks for "low 4x4 only" until a test fails
@@ -534,17 +624,30 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
   asm volatile("" ::"v"(cur.d[0]), "v"(cur.d[1]), "v"(cur.d[2]), "v"(cur.d[3]), "v"(cur.d[4]), "v"(cur.d[5]),
                "v"(cur.d[6]), "v"(cur.d[7]), "v"(cur.d[8]), "v"(pos_n));
 
-  for (int it = 0; it < kDecIters; it++) {
-    const uint32_t grp_n = grp + slots;
-    const bool have_n = it + 1 < kDecIters && grp_n < ngroups;  // wave-uniform
-    const uint32_t mb_n = grp_n * (uint32_t)kMbPerGroup + dmb;
-    const bool valid_n = have_n && mb_n < f.nmb;
+  MIRTJ_STAMP(0);  // prologue: descriptor, table, first offsets and bytes
+  for (uint32_t it = 0;; it++) {
+    const bool have_n = more_after(it);  // wave-uniform
+    const bool valid = s0.valid, valid_n = have_n && s1.valid;
+    const uint32_t grp = s0.grp, dmb = s0.dmb, kblk = s0.kblk, mb = s0.mb;
     pos_n = valid_n ? pos_n : 0u;
 
     const uint32_t sh = (uint32_t)((uintptr_t)(data + pos0) & 3u);
     uint32_t d0 = cur.d[0], d1 = cur.d[1], d2 = cur.d[2], d3 = cur.d[3], d4 = cur.d[4];
     // unchanged block: previous pixels stay (lib/RTjpeg.c:2704)
-    const bool live_blk = valid && (__builtin_amdgcn_alignbyte(d1, d0, sh) & 0xFFu) != 0xFFu;
+    const bool live_any = valid && (__builtin_amdgcn_alignbyte(d1, d0, sh) & 0xFFu) != 0xFFu;
+
+    // ---- enough "DC only" blocks in this group?  Then those are filled in at once and the others put off: they
+    // are taken 64 at a time by k_decode_list, instead of a transform round here with most lanes idle ----
+    bool dc_only = false, put_off = false;
+    if (dc_test) {
+      const unsigned long long b_lo = (unsigned long long)__builtin_amdgcn_alignbyte(d2, d1, sh) << 32 |
+                                      __builtin_amdgcn_alignbyte(d1, d0, sh);
+      const unsigned long long b_hi = (unsigned long long)__builtin_amdgcn_alignbyte(d4, d3, sh) << 32 |
+                                      __builtin_amdgcn_alignbyte(d3, d2, sh);
+      dc_only = live_any && (((b_lo & dcm_lo) ^ dcp_lo) | ((b_hi & dcm_hi) ^ dcp_hi)) == 0ull;
+      put_off = (uint32_t)__builtin_popcountll(__ballot(dc_only)) >= kDcDeferMin;  // wave-uniform
+    }
+    const bool live_blk = live_any && !put_off;  // the lanes of this iteration's transform round, if there is one
 
     if (live_blk) {
       // ---- stream -> dequantised coefficients, int16, transposed (lib/RTjpeg.c:157-186) ----
@@ -633,6 +736,7 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
       }
     }
 
+    MIRTJ_STAMP(1);  // classification + parse
     // ---- request the next group's stream bytes and the block offset of the group after it: they arrive while
     // this group is transformed ----
     typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -640,10 +744,11 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
     uint32_t nb2, pos_nn;
     Bytes near_end;  // the next group's bytes when they were fetched with masks (end of the packet)
     bool inside_n = false;
+    Src s2 = s1;
     if (have_n) {
       inside_n = !kForceGenericPaths && __all(pos_n + kFetchSpan <= f.data_len);
-      const uint32_t mb_nn = (grp_n + slots) * (uint32_t)kMbPerGroup + dmb;
-      const uint32_t* offp = off + (it + 2 < kDecIters && mb_nn < f.nmb ? 6u * mb_nn + kblk : 0u);
+      s2 = source(it + 2u);
+      const uint32_t* offp = off + (s2.valid ? 6u * s2.mb + s2.kblk : 0u);
       const uint8_t* g = data + pos_n;
       const uint32_t* g4 = (const uint32_t*)(g - ((uintptr_t)g & 3u));
       if (!inside_n) {  // near the packet's end: masked loads, waited for at once (rare); the hand-issued loads
@@ -682,14 +787,15 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
       try_lo = lo;
     }
 
-    if (live_blk) {
+    MIRTJ_STAMP(2);  // look-ahead loads issued, low-4x4 test
+    if (live_any) {
       // macroblock coordinates without a per-lane division: one scalar division for the group's
       // first macroblock, then at most one row wrap per lane when rows are at least a group wide
       uint32_t mx, my_;
       {
         const uint32_t mbw = f.mbw, mb0 = grp * (uint32_t)kMbPerGroup;
         const uint32_t gy = mb0 / mbw, gx = mb0 - gy * mbw;  // uniform
-        if (mbw >= (uint32_t)kMbPerGroup) {
+        if (!kList && mbw >= (uint32_t)kMbPerGroup) {
           const bool wrap = gx + dmb >= mbw;
           mx = wrap ? gx + dmb - mbw : gx + dmb;
           my_ = wrap ? gy + 1u : gy;
@@ -724,7 +830,25 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
         dst += stride;
       };
 
-      if (lo) {
+      if (put_off) {
+        // ---- this group's DC-only blocks: one pixel value, eight rows of it; the other live blocks are left to
+        // k_decode_list (their lane mask goes out below) ----
+        if (dc_only) {
+          const uint32_t b0 = __builtin_amdgcn_alignbyte(d1, d0, sh) & 0xFFu;
+          const int v = (int)(int16_t)(b0 * (uint32_t)q_dc) + 4;  // the product is stored as int16 (lib/RTjpeg.c:163)
+          const uint32_t p1 = px(v);
+          const uint32_t p4 = p1 * 0x01010101u;
+          typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+          u32x2_t ov;
+          ov.x = p4;
+          ov.y = p4;
+#pragma unroll
+          for (int r = 0; r < 8; r++) {
+            __builtin_nontemporal_store(ov, (u32x2_t*)dst);
+            dst += stride;
+          }
+        }
+      } else if (lo) {
         uint2 ql[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) ql[c] = *(const uint2*)((const uint8_t*)my + 16 * c);
@@ -794,27 +918,36 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
         }
       }
     }
+    MIRTJ_STAMP(3);  // coordinates, transform, row stores
+    // the lanes put off, for k_decode_list: one mask per iteration (the buffer is zeroed before every launch)
+    const unsigned long long m_off = __ballot(live_any && put_off && !dc_only);
+    if (put_off && lane == 0) my_defer[it] = m_off;
     if (!have_n) break;
-    // Every transform variant ends with eight row stores, so behind the join "all but the 8 youngest operations"
-    // is exactly "everything requested before the transform" — unless no lane had a live block: such a wave
-    // stored nothing and waits for all there is.
+    // Every transform variant ends with eight row stores, the fill of DC-only blocks is eight stores and the mask
+    // one more, so behind the join "all but the 8 (9) youngest operations" is exactly "everything requested before
+    // the transform" — unless no lane had a live block: such a wave stored nothing and waits for all there is.
     {
-      const unsigned long long any_live = __ballot(live_blk);
+      const uint32_t younger = put_off ? 9u : __ballot(live_any) != 0ull ? 8u : 0u;
       asm volatile(
-          "s_cmp_eq_u64 %4, 0\n\t"
-          "s_cbranch_scc1 .Lmirtj_nolive_%=\n\t"
+          "s_cmp_eq_u32 %4, 8\n\t"
+          "s_cbranch_scc1 .Lmirtj_w8_%=\n\t"
+          "s_cmp_eq_u32 %4, 9\n\t"
+          "s_cbranch_scc1 .Lmirtj_w9_%=\n\t"
+          "s_waitcnt vmcnt(0)\n\t"
+          "s_branch .Lmirtj_arrived_%=\n"
+          ".Lmirtj_w8_%=:\n\t"
           "s_waitcnt vmcnt(8)\n\t"
           "s_branch .Lmirtj_arrived_%=\n"
-          ".Lmirtj_nolive_%=:\n\t"
-          "s_waitcnt vmcnt(0)\n"
+          ".Lmirtj_w9_%=:\n\t"
+          "s_waitcnt vmcnt(9)\n"
           ".Lmirtj_arrived_%=:"
           : "+v"(nb0), "+v"(nb1), "+v"(nb2), "+v"(pos_nn)
-          : "s"(any_live)
+          : "s"(younger)
           : "scc", "memory");
     }
-    grp = grp_n;
-    mb = mb_n;
-    valid = valid_n;
+    MIRTJ_STAMP(4);  // the counted wait for the look-ahead loads
+    s0 = s1;
+    s1 = s2;
     pos0 = pos_n;
     pos_n = pos_nn;
     if (inside_n) {
@@ -826,6 +959,46 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
     }
     inside = inside_n;
   }
+#ifdef MIRTJ_STAMPS
+  if (lane == 0) {
+    const int base = chroma ? 0 : 0;
+    for (int i = 0; i < 5; i++) atomicAdd(&g_stamps[base + i], st_acc[i]);
+    atomicAdd(&g_stamps[5], 1ull);
+  }
+#endif
+}
+
+// k_decode: see above.  `defer` = nullptr: no group's blocks are put off (every live block is transformed here).
+__global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const FrameDev* __restrict__ frames,
+                                                         const uint8_t* __restrict__ stream,
+                                                         const QTab* __restrict__ lut,
+                                                         const uint32_t* __restrict__ blkoff,
+                                                         uint8_t* __restrict__ outbuf,
+                                                         unsigned long long* __restrict__ defer) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_lds[kDecLdsWords];
+  decode_wave<false>(s_lds, frames, stream, lut, blkoff, outbuf, defer);
+}
+
+// k_decode_list: same grid; the wave (slot, part, frame) takes the blocks its k_decode twin put off, 64 per round —
+// block starts and destinations follow from (iteration, lane) as in k_decode, so the list is 8 bytes per wave and
+// iteration.  Rows are stored 8 bytes per lane at unrelated addresses (the blocks are no longer neighbours).
+__global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode_list(const FrameDev* __restrict__ frames,
+                                                              const uint8_t* __restrict__ stream,
+                                                              const QTab* __restrict__ lut,
+                                                              const uint32_t* __restrict__ blkoff,
+                                                              uint8_t* __restrict__ outbuf,
+                                                              unsigned long long* __restrict__ defer) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_lds[kDecLdsWords + kDecListWords];
+  decode_wave<true>(s_lds, frames, stream, lut, blkoff, outbuf, defer);
+}
+
+// set bits of a word array (mi_rtj_plan_deferred: blocks put off by the last k_decode)
+__global__ __launch_bounds__(256) void k_count_bits(const unsigned long long* __restrict__ w, size_t n,
+                                                     unsigned long long* __restrict__ sum) {
+  unsigned long long acc = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    acc += (unsigned long long)__builtin_popcountll(w[i]);
+  if (acc) atomicAdd(sum, acc);
 }
 
 }  // namespace mirtj

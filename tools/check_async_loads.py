@@ -26,14 +26,14 @@ def all_vregs(line):
     return out
 
 
-def check(path, kernel="k_decode"):
+def check(path, kernel="k_decode", fills=4, singles=1):
+    """fills: basic blocks that must hold exactly eight stores (three transform variants + the DC-only fill in
+    k_decode; three in k_decode_list); singles: blocks with one store (the put-off mask)."""
     lines = open(path).read().split("\n")
-    start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN5mirtj\d+" + kernel + r"E", l) and l.rstrip().endswith(("Ph", ":")) or
-                 (re.match(r"^_ZN5mirtj\d+" + kernel + r"E.*:", l)))
+    start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN5mirtj\d+" + kernel + r"E.*:", l))
     end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
     body = lines[start:end]
-    # the hand-issued block: an ASMSTART region that holds global_load_dwordx4 (there is exactly one such region
-    # inside the group loop)
+    # the hand-issued block: the ASMSTART region that holds global_load_dwordx4 (exactly one, inside the group loop)
     blocks = []
     i = 0
     while i < len(body):
@@ -41,13 +41,12 @@ def check(path, kernel="k_decode"):
             j = i
             while "#ASMEND" not in body[j]:
                 j += 1
-            txt = body[i:j]
-            if any("global_load_dwordx4" in t for t in txt):
+            if any("global_load_dwordx4" in t for t in body[i:j]):
                 blocks.append((i, j))
             i = j
         i += 1
     if len(blocks) != 1:
-        return [f"expected one hand-issued load block, found {len(blocks)}"]
+        return [f"{kernel}: expected one hand-issued load block, found {len(blocks)}"]
     b0, b1 = blocks[0]
     pending = set()
     for t in body[b0:b1]:
@@ -55,9 +54,8 @@ def check(path, kernel="k_decode"):
         if t.startswith("global_load"):
             pending |= regs_of(t.split()[1].rstrip(","))
     errs = []
-    # scan forward from the loads to the hand-placed wait block (s_waitcnt vmcnt(8) inside an ASMSTART region)
     waited = False
-    stores_by_path = []
+    per_block = []
     stores = 0
     for k in range(b1 + 1, len(body)):
         raw = body[k]
@@ -66,17 +64,25 @@ def check(path, kernel="k_decode"):
             j = k
             while "#ASMEND" not in body[j]:
                 j += 1
-            if any("s_waitcnt vmcnt(8)" in x for x in body[k:j]):
-                if not any("s_waitcnt vmcnt(0)" in x for x in body[k:j]):
+            txt = body[k:j]
+            if any("s_waitcnt vmcnt(8)" in x for x in txt):
+                if not any("s_waitcnt vmcnt(0)" in x for x in txt):
                     errs.append(f"line {k}: the wait block has no vmcnt(0) arm for waves that stored nothing")
+                if singles and not any("s_waitcnt vmcnt(9)" in x for x in txt):
+                    errs.append(f"line {k}: the wait block has no vmcnt(9) arm for groups that were put off")
                 waited = True
                 break
-        if not t or t.endswith(":") or t.startswith("."):
-            if t.endswith(":") and stores:
-                stores_by_path.append(stores)
-                stores = 0
+        if not t or t.startswith("."):
+            continue
+        if t.endswith(":"):
+            per_block.append(stores)
+            stores = 0
             continue
         op = t.split()[0]
+        if op.startswith(("s_cbranch", "s_branch")):
+            per_block.append(stores)
+            stores = 0
+            continue
         if op == "s_waitcnt" and "vmcnt" in t:
             errs.append(f"line {k}: compiler-placed '{t}' while hand-issued loads are pending")
             continue
@@ -90,17 +96,18 @@ def check(path, kernel="k_decode"):
         touched = all_vregs(t) & pending
         if touched:
             errs.append(f"line {k}: '{t}' touches pending v{sorted(touched)}")
-    if stores:
-        stores_by_path.append(stores)
+    per_block.append(stores)
     if not waited:
         errs.append("hand-placed wait block not found behind the loads")
-    if any(n != 8 for n in stores_by_path) or not stores_by_path:
-        errs.append(f"row stores per transform variant: {stores_by_path} (the counted wait assumes 8 on every path)")
-    return errs
+    nz = sorted(n for n in per_block if n)
+    if nz != [1] * singles + [8] * fills:
+        errs.append(f"{kernel}: stores per basic block between the loads and the wait: {nz}; expected "
+                    f"{[1] * singles + [8] * fills} (the counted waits assume them)")
+    return [f"{kernel}: {e}" if not e.startswith(kernel) else e for e in errs]
 
 
 if __name__ == "__main__":
-    e = check(sys.argv[1])
+    e = check(sys.argv[1], "k_decode", 4, 1) + check(sys.argv[1], "k_decode_list", 3, 0)
     for x in e:
         print("ASYNC-LOAD CHECK:", x)
     print("pending-load check:", "clean" if not e else f"{len(e)} problem(s)")

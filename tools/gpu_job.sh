@@ -1,9 +1,4 @@
 set -u
-mkdir -p gpurun_out/r02a
-(timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r02a/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r02a/pytest.log; tail -3 gpurun_out/r02a/pytest.log)
-bash tools/ab_libs.sh 2 -- lib_r1base.so product > gpurun_out/r02a/ab.txt 2>&1
-cat gpurun_out/r02a/ab.txt
-tools/ubench/valu_kinds2 4 > gpurun_out/r02a/valu_kinds2_4w.txt 2>&1
-tools/ubench/valu_kinds2 8 > gpurun_out/r02a/valu_kinds2_8w.txt 2>&1
-tools/ubench/valu_kinds2 2 > gpurun_out/r02a/valu_kinds2_2w.txt 2>&1
-echo done
+mkdir -p gpurun_out/r02g
+for w in 1 2 4 8; do tools/ubench/valu_snop $w > gpurun_out/r02g/valu_snop_${w}w.txt; done
+paste -d'|' gpurun_out/r02g/valu_snop_1w.txt gpurun_out/r02g/valu_snop_2w.txt gpurun_out/r02g/valu_snop_4w.txt gpurun_out/r02g/valu_snop_8w.txt | awk -F'|' '{split($1,a," ns"); split($2,b," ns"); split($3,c," ns"); split($4,e," ns"); n=split(a[1],x," "); m=split(b[1],y," "); o=split(c[1],z," "); q=split(e[1],u," "); printf "%-38s 1w %s 2w %s 4w %s 8w %s\n", substr($1,1,38), x[n], y[m], z[o], u[q]}'
