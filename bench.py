@@ -1,27 +1,46 @@
 #!/usr/bin/env python3
-"""bench.py — RTjpeg 1080p decode throughput on MI355X (BASELINE.json's metric).
+"""bench.py — RTjpeg decode throughput on MI355X (BASELINE.json's metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config frames1080|streams4k|mixed]
 
-A "step" is one pass of the whole hot path (block-offset index + dequant/IDCT/plane scatter) over
-one batch of `--frames` distinct synthetic RTjpeg frames that are already resident in HBM
-(coded 1920x1088 = display 1080p, YUV420, Q=255, intra only; SURVEY.md §8d cfg 2).  Frames,
-streams and outputs never leave the device inside the timed region.
+With --gpus N > 1 and no WORLD_SIZE in the environment this process starts the N ranks itself (one process per
+GPU, `python -m torch.distributed.run`, rendezvous on 127.0.0.1) before anything touches a GPU, passes rank 0's
+line through and exits with the ranks' status.  A world size that differs from --gpus is an error, never a
+silent one-rank run.
 
-One process per GPU (RANK/LOCAL_RANK/WORLD_SIZE from the environment when launched by
-torch.distributed.run).  The path shards by frame with no data-path collective (weak scaling: every
-rank decodes its own `--frames` frames); RCCL is used only for the barrier and the final
-(frames, max elapsed) reduction.
+Workloads (`config.workload` in the output names the one that ran):
+  frames1080  (default; BASELINE configs[1]) a "step" is one pass of the whole hot path (block-offset index +
+              dequant/IDCT/plane scatter) over `--frames` distinct synthetic RTjpeg frames per GPU that are already
+              resident in HBM (coded 1920x1088 = display 1080p, YUV420, Q=255, intra only; SURVEY.md §8d cfg 2).
+              Frames, streams and outputs never leave the device inside the timed region.  Weak scaling.
+  streams4k   (configs[3]) one 3840x2160 stream WITH unchanged (0xFF) blocks per GPU, decoded in order, one packet
+              per call, through the entry point the plugin uses (host packet in, host planes out: PCIe included).
+              A step is one pass over the stream's `--frames` packets.
+  mixed       (configs[4]) 64 intra-only streams of mixed geometry and quality, frames dealt cyclically to the
+              ranks, one plan per rank, every frame of every rank compared with the CPU oracle.
+
+One process per GPU.  No data-path collective: RCCL carries the barrier and the final (frames, pixels,
+mismatches, max elapsed) reduction only.
 
 Rank 0 prints ONE JSON line: the contract fields plus
-  "roofline":     dominant kernel of the path, algorithmic bytes / its HIP-event time vs HBM peak
-  "cpu_baseline": the reference's lib/RTjpeg.c (oracle/_ref, kind "reference") or the oracle port,
-                  one thread, timed on this box on a bounded sample of the same packets.
+  "roofline":      dominant kernel of the path, algorithmic bytes / its HIP-event time vs HBM peak; `traffic` = HBM
+                   bytes per launch from the committed PMC profile, only while that profile was taken from the same
+                   kernel sources (else null)
+  "roofline_valu": the same kernel against the vector-issue roof: instructions per launch (PMC) x measured cost per
+                   instruction / measured time
+  "cpu_baseline":  the reference's lib/RTjpeg.c (oracle/_ref, kind "reference") or the oracle port, one thread, timed
+                   on this box on a bounded sample of the same packets; "cpu_baseline_all_cores": one decoder per core
+  "parity_checked" / "parity_mismatches": frames of this run compared with the CPU decoder, all of the sample
+The process exits non-zero when a compared frame differs.
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -29,6 +48,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+# what one wave64 vector instruction costs a SIMD while instructions of the slower class are in flight on it, which
+# in k_decode is always (tools/ubench/valu_mix*.hip, valu_stagger.hip; profiles/r02/ubench_valu.txt): 1.80 ns
+VALU_NS_MIXED = 1.80
+SIMDS = 256 * 4
 
 
 def parse():
@@ -36,97 +59,197 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=4096, help="distinct frames resident per GPU")
+    ap.add_argument("--config", choices=["frames1080", "streams4k", "mixed"], default="frames1080")
+    ap.add_argument("--frames", type=int, default=None, help="frames resident per GPU (frames1080: 4096) / per stream")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1088)
     ap.add_argument("--quality", type=int, default=255)
     ap.add_argument("--amp", type=int, default=8, help="noise amplitude of the synthetic content")
     ap.add_argument("--seed", type=int, default=12345)
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline leg")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--cpu-all-cores", action="store_true",
-                    help="also time one reference decoder per host core of this process's share (extra field)")
-    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=6.0, help="budget of each CPU baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU legs (and with them the parity check)")
+    ap.add_argument("--no-stress", action="store_true", help="skip the short second measurement on noisy content")
+    ap.add_argument("--verify-frames", type=int, default=256, help="frames of the batch compared with the CPU decoder")
+    ap.add_argument("--selftest-ranks", action="store_true",
+                    help="no GPU work: every rank reports a dummy shard through the same reduction (launcher test)")
     return ap.parse_args()
 
 
-def cpu_baseline(pkts, w, h, budget_s, gpu_planes):
-    """Times the reference decoder (or the oracle port) on this box's host cores, one thread, exactly
-    as decode_rtjpeg calls it: RTjpeg_decompress into the private frame, then one full-frame copy
+# --------------------------------------------------------------------------- rank launcher
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(a):
+    """--gpus N without a launcher around us: start the N ranks here.  Nothing has touched a GPU yet."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env)
+    raise SystemExit(r.returncode)
+
+
+# --------------------------------------------------------------------------- CPU side (checker + baseline)
+def _cpu_decoder(w, h):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import rtjlib as R  # the checker; used here only as the measured CPU baseline and the parity check
+    if R.have_reference():
+        dec = R.RefCodec()
+        dec.w, dec.h_ = w, h
+
+        def run(pkt, out):
+            dec.L.RTjpeg_decompress(dec.h, R._ptr(pkt), R._planes_arg(out, w, h))
+        return "reference", run, dec
+    dec = R.OracleDecoder()
+
+    def run(pkt, out):
+        dec.decode(pkt, out)
+    return "port", run, dec
+
+
+def _cpu_worker(args):
+    """One core: decodes its slice of the sample once (digests for the parity check), then keeps decoding for the
+    budget exactly as decode_rtjpeg does it: RTjpeg_decompress into the private frame, then one full-frame copy
     (gavl_video_frame_copy, lib/video_rtjpeg.c:81-82)."""
     import numpy as np
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import rtjlib as R  # the checker; used here only as the measured CPU baseline
+    pkts, w, h, budget_s = args
+    kind, run, _keep = _cpu_decoder(w, h)
     fsz = w * h * 3 // 2
-    if R.have_reference():
-        kind, dec = "reference", R.RefCodec()
-        dec.w, dec.h_ = w, h
-        padded = [np.concatenate([p, np.zeros(4096, np.uint8)]) for p in pkts]
-
-        def run(i, out):
-            dec.L.RTjpeg_decompress(dec.h, R._ptr(padded[i]), R._planes_arg(out, w, h))
-    else:
-        kind, dec = "port", R.OracleDecoder()
-
-        def run(i, out):
-            dec.decode(pkts[i], out)
-    priv = np.zeros(fsz, np.uint8)
-    user = np.zeros(fsz, np.uint8)
-    mismatches = 0
-    for i, want in gpu_planes.items():  # untimed: the CPU result is also the parity check of this run
-        run(i, priv)
-        mismatches += int(not np.array_equal(priv, want))
+    padded = [np.concatenate([p, np.zeros(4096, np.uint8)]) for p in pkts]
+    priv, user = np.zeros(fsz, np.uint8), np.zeros(fsz, np.uint8)
+    digests = []
+    for p in padded:
+        run(p, priv)
+        digests.append(hashlib.sha256(priv.tobytes()).hexdigest()[:32])
     done, t0 = 0, time.perf_counter()
-    while True:
-        for i in range(len(pkts)):
-            run(i, priv)
+    while budget_s > 0 and padded:
+        for p in padded:
+            run(p, priv)
             np.copyto(user, priv)
             done += 1
             if time.perf_counter() - t0 > budget_s:
                 break
-        if time.perf_counter() - t0 > budget_s or done >= 64 * len(pkts):
+        if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return {"value": round(done / dt, 2), "unit": "frames/s", "cores": 1, "kind": kind,
-            "sample": f"{done} frames of the same {w}x{h} packets, decode + one frame copy, {dt:.1f} s, "
-                      f"host has {os.cpu_count()} logical cores",
-            "mpixels_per_s": round(done * w * h / dt / 1e6, 1)}, mismatches
+    return kind, digests, done, dt
 
 
-def _cpu_worker(args):
-    pkts, w, h, budget_s = args
-    return cpu_baseline(pkts, w, h, budget_s, {})[0]["value"]
-
-
-def cpu_baseline_all_cores(pkts, w, h, budget_s):
-    """One reference decoder per core this process may use (one stream each, as independent bgav instances
-    would run): the honest "whole host share" figure of SURVEY.md section 8d."""
+def cpu_legs(pkts, w, h, budget_s, gpu_digests):
+    """(cpu_baseline, cpu_baseline_all_cores, frames compared, mismatches).  The sample is dealt to one process per
+    core this process may use; each decodes its share once for the comparison, then runs the timed loop.  The
+    one-core figure is timed separately, on its own (nothing else running)."""
     import multiprocessing as mp
-    cores = len(os.sched_getaffinity(0))
+    cores = max(1, len(os.sched_getaffinity(0)))
+    kind, _, done1, dt1 = _cpu_worker((pkts[: min(len(pkts), 16)], w, h, budget_s))
+    one = {"value": round(done1 / dt1, 2), "unit": "frames/s", "cores": 1, "kind": kind,
+           "sample": f"{done1} decodes of {min(len(pkts), 16)} of the same {w}x{h} packets, decode + one frame copy, "
+                     f"{dt1:.1f} s, host has {os.cpu_count()} logical cores",
+           "mpixels_per_s": round(done1 * w * h / dt1 / 1e6, 1)}
+    shares = [pkts[i::cores] for i in range(cores)]
     with mp.get_context("spawn").Pool(cores) as pool:
-        vals = pool.map(_cpu_worker, [(pkts[: min(len(pkts), 8)], w, h, budget_s)] * cores)
-    return {"value": round(sum(vals), 1), "unit": "frames/s", "cores": cores, "kind": "reference"
-            if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "librtjpeg_ref.so")) else "port",
-            "sample": f"{cores} processes, one decoder each, {budget_s:.0f} s, same packets"}
+        res = pool.map(_cpu_worker, [(s, w, h, budget_s) for s in shares])
+    mism, checked = 0, 0
+    for i, (_, digs, _, _) in enumerate(res):
+        for j, d in enumerate(digs):
+            k = i + j * cores
+            checked += 1
+            mism += int(d != gpu_digests[k])
+    allc = {"value": round(sum(r[2] / r[3] for r in res if r[3] > 0), 1), "unit": "frames/s", "cores": cores,
+            "kind": kind, "sample": f"{cores} processes, one decoder each, {budget_s:.0f} s, shares of the same "
+                                    f"{len(pkts)} packets"}
+    return one, allc, checked, mism
+
+
+# --------------------------------------------------------------------------- PMC profile of the same sources
+def kernel_source_digest():
+    """Identifies the kernel sources a PMC profile belongs to (profiles/traffic.json carries the digest it was
+    taken with; tools/make_traffic.py writes it)."""
+    hsh = hashlib.sha256()
+    csrc = os.path.join(ROOT, "gmerlin-avdecoder_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".h", ".hip", ".cpp")) and ("kernels" in name or "idct" in name or name == "rtj_common.h"):
+            hsh.update(open(os.path.join(csrc, name), "rb").read())
+    return hsh.hexdigest()[:16]
+
+
+def pmc_profile():
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        tj = json.load(open(path))
+    except Exception:
+        return None
+    tj["_current"] = tj.get("source_digest") == kernel_source_digest()
+    return tj
+
+
+# --------------------------------------------------------------------------- workloads
+def run_frames(a, dev, rank, n, amp, steps, warmup, barrier, sync_all):
+    """The resident-batch workload: returns everything rank 0 needs for its line."""
+    import numpy as np
+    w, h, Q = a.width, a.height, a.quality
+    fsz = w * h * 3 // 2
+    d_fr = dev.synth(w, h, rank * n, n, seed=a.seed, amp=amp)
+    d_st, po, pl = dev.encode(w, h, Q, n, d_fr)
+    dev.sync()
+    dev.free(d_fr)
+    hdr0 = dev.d2h(d_st, 12, offset=int(po[0]))
+    oo = np.arange(n, dtype=np.uint64) * np.uint64(fsz)
+    d_out = dev.alloc(fsz * n)
+    plan = dev.plan(np.tile(hdr0, (n, 1)), po, pl, oo)
+    info = plan.info()
+    for _ in range(warmup):
+        plan.decode(d_st, d_out)
+    dev.sync()
+    plan.profile(True)
+    barrier()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        plan.decode(d_st, d_out)
+    sync_all()
+    barrier()
+    dt = time.perf_counter() - t0
+    ktimes, launches = plan.times()
+    step_ms = plan.step_times()
+    plan.profile(False)
+    return dict(plan=plan, info=info, dt=dt, ktimes=ktimes, launches=launches, step_ms=step_ms, d_st=d_st, d_out=d_out,
+                po=po, pl=pl, fsz=fsz, n=n)
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(a)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: refusing to report a run of another size")
+
+    shard = importlib.import_module("gmerlin-avdecoder_amd.shard")
+    backend = os.environ.get("MI_RTJ_DIST_BACKEND", "nccl")
+    if a.selftest_ranks:  # launcher + reduction only, no GPU: what tests/test_bench_launcher.py runs on a CPU box
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        rep = shard.reduce_report(shard.Report(10 + rank, (10 + rank) * 100, 0, 1.0 + rank), dist)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"metric": "selftest", "n_gpus": world, "frames": rep.frames, "elapsed": rep.elapsed}), flush=True)
+        dist.destroy_process_group()
+        return
 
     import numpy as np
     import torch
     dist = None
     # MI_RTJ_DIST_BACKEND=gloo + MI_RTJ_SHARE_DEVICE=1 rehearse the multi-rank flow on a one-GPU box
     # (all ranks on device 0, reduction over gloo); the real run is one rank per GPU over RCCL.
-    backend = os.environ.get("MI_RTJ_DIST_BACKEND", "nccl")
     gpu = 0 if os.environ.get("MI_RTJ_SHARE_DEVICE") else local
-    # MI_RTJ_FORCE_DIST=1: take the process-group path even with one rank (rehearses RCCL on a one-GPU box)
-    force_dist = bool(os.environ.get("MI_RTJ_FORCE_DIST"))
+    force_dist = bool(os.environ.get("MI_RTJ_FORCE_DIST"))  # the process-group path even with one rank
     if world > 1 or force_dist:
         import torch.distributed as dist
         torch.cuda.set_device(gpu)
@@ -137,74 +260,56 @@ def main():
     P = importlib.import_module("gmerlin-avdecoder_amd")
     dev = P.MiRtj(gpu)  # raises if the HIP library or the device is missing: no CPU fallback
 
-    w, h, Q, n = a.width, a.height, a.quality, a.frames
-    fsz = w * h * 3 // 2
-    # ---- untimed: make this rank's frames and streams on the device ----
-    first = rank * n
-    d_fr = dev.synth(w, h, first, n, seed=a.seed, amp=a.amp)
-    d_st, po, pl = dev.encode(w, h, Q, n, d_fr)
-    dev.sync()
-    dev.free(d_fr)
-    hdr0 = dev.d2h(d_st, 12, offset=int(po[0]))
-    hdrs = np.tile(hdr0, (n, 1))
-    oo = np.arange(n, dtype=np.uint64) * np.uint64(fsz)
-    d_out = dev.alloc(fsz * n)
-    plan = dev.plan(hdrs, po, pl, oo)
-    info = plan.info()
-
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(a.warmup):
-        plan.decode(d_st, d_out)
-    dev.sync()
-    plan.profile(True)
-    barrier()
-    torch.cuda.synchronize()
-    dev.sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        plan.decode(d_st, d_out)
-    dev.sync()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    ktimes, launches = plan.times()
-    plan.profile(False)
+    def sync_all():
+        dev.sync()
+        torch.cuda.synchronize()
+
+    red_dev = f"cuda:{gpu}" if dist is not None and backend == "nccl" else None
+    if a.config != "frames1080":
+        mod = importlib.import_module("gmerlin-avdecoder_amd.bench_configs")
+        out, mism = mod.run(a, dev, P, shard, dist, red_dev, rank, world, barrier, sync_all, force_dist)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        dev.close()
+        if dist is not None:
+            dist.destroy_process_group()
+        if mism:
+            raise SystemExit(3)
+        return
+
+    w, h, Q = a.width, a.height, a.quality
+    n = a.frames or 4096
+    r = run_frames(a, dev, rank, n, a.amp, a.steps, a.warmup, barrier, sync_all)
+    plan, info, fsz = r["plan"], r["info"], r["fsz"]
 
     # the only collective of the path: SUM(frames, pixels, mismatches), MAX(elapsed) — a few bytes over RCCL
-    shard = importlib.import_module("gmerlin-avdecoder_amd.shard")
-    rep = shard.reduce_report(shard.Report(n, n * w * h, 0, dt), dist,
-                              device=f"cuda:{gpu}" if dist is not None and backend == "nccl" else None,
-                              force=force_dist)
+    rep = shard.reduce_report(shard.Report(n, n * w * h, 0, r["dt"]), dist, device=red_dev, force=force_dist)
     tot_frames, dt = rep.frames, rep.elapsed
-
+    mismatches = 0
     if rank == 0:
         fps = tot_frames * a.steps / dt
-        # per-launch figures of every kernel of the path (this rank), from HIP events on the launch stream
         alg_bytes = info["bytes_in"] + info["bytes_out"]  # packet read once + planes written once
         alg = {"k_index_summarize": info["bytes_in"], "k_index_resolve": 0, "k_index_emit": info["bytes_in"],
                "k_decode": alg_bytes, "k_spec_walk": info["bytes_in"], "k_spec_verify": 0}
         kernels = {}
-        for name, ms in ktimes.items():
-            per = ms / max(launches, 1)
+        for name, ms in r["ktimes"].items():
+            per = ms / max(r["launches"], 1)
             if per <= 0:
                 continue
-            kernels[name] = {"ms": round(per, 4), "alg_bytes": alg[name],
-                             "gbs": round(alg[name] / (per * 1e-3) / 1e9, 2)}
+            worked = per > 0.05 and alg[name] > 0  # a kernel that returned at once on an empty to-do list moved nothing
+            kernels[name] = {"ms": round(per, 4), "alg_bytes": alg[name] if worked else None,
+                             "gbs": round(alg[name] / (per * 1e-3) / 1e9, 2) if worked else None}
         dom = max(kernels, key=lambda k: kernels[k]["ms"])
         ach = kernels[dom]["gbs"] or 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))  # PMC bytes per launch of tj["frames_per_launch"] frames; linear in frames
-                traffic = int(tj[dom] * n / tj.get("frames_per_launch", 256)) if dom in tj else None
-            except Exception:
-                traffic = None
-        # the north star's kernel of interest, whatever dominates: IDCT + plane scatter
+        prof = pmc_profile()
+        scale = n / prof.get("frames_per_launch", n) if prof else 0.0
+        traffic = int(prof[dom] * scale) if prof and prof["_current"] and dom in prof else None
         dec = kernels.get("k_decode", {"gbs": 0.0, "ms": 0.0})
+        med = statistics.median(r["step_ms"]) if r["step_ms"] else None
         out = {
             "metric": "RTjpeg 1080p decode frames/sec", "value": round(fps, 1), "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -215,10 +320,16 @@ def main():
                        "frames_per_gpu": n, "avg_packet_bytes": int(info["bytes_in"] // n),
                        "sharding": "frames, no data-path collective"},
             "mpixels_per_s": round(fps * w * h / 1e6, 1),
+            "median_step": {"device_ms": round(med, 4) if med else None,
+                            "frames_per_s_per_gpu": round(n / (med * 1e-3), 1) if med else None,
+                            "note": "median over the timed steps of first-kernel-start to k_decode-end (HIP events, rank 0); "
+                                    "`value` is the contract's whole-run figure"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_source": (f"profiles/traffic.json ({prof.get('note', '')})" if traffic is not None else
+                                            "none: the committed PMC profile was not taken from these kernel sources"),
                          "alg_bytes_per_launch": kernels[dom]["alg_bytes"], "ms_per_launch": kernels[dom]["ms"],
-                         "note": "integer-VALU-issue bound, not HBM bound: DESIGN.md section 5"},
+                         "note": "vector-issue bound, not HBM bound: roofline_valu and DESIGN.md section 5"},
             "roofline_decode": {"bound": "hbm", "kernel": "k_decode", "achieved": dec["gbs"], "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": round((dec["gbs"] or 0.0) / HBM_PEAK_GBS, 5),
                                 "ms_per_launch": dec["ms"], "alg_bytes_per_launch": alg_bytes},
@@ -227,30 +338,61 @@ def main():
             "speculative_index": dict(zip(("packets_proven", "stream_chunks"), plan.spec_stats()),
                                       chunks_repaired=getattr(plan, "repaired", 0),
                                       walker_lead_bytes=plan.spec_lead()[0]),  # what the policy chose for the next launch
+            "blocks_put_off": plan.deferred(),
             "path_gbs": round(alg_bytes * a.steps / dt / 1e9, 2),
         }
+        # the vector-issue roof of k_decode: instructions per launch from the PMC profile of these sources
+        vi = prof.get("valu_instructions", {}).get("k_decode") if prof and prof["_current"] else None
+        if vi and dec["ms"]:
+            need_ms = vi * scale * VALU_NS_MIXED / SIMDS * 1e-6
+            out["roofline_valu"] = {"bound": "valu-issue", "kernel": "k_decode", "instructions_per_launch": int(vi * scale),
+                                    "ns_per_instruction_per_simd": VALU_NS_MIXED, "simds": SIMDS,
+                                    "floor_ms": round(need_ms, 4), "measured_ms": dec["ms"],
+                                    "frac": round(need_ms / dec["ms"], 4),
+                                    "note": "wave64 vector instructions x what one costs a SIMD while expensive-class "
+                                            "instructions are in flight (tools/ubench/valu_mix.hip) / SIMDs; frac = how close "
+                                            "k_decode runs to that roof"}
         if world == 1 and not a.no_cpu:
-            ns = min(n, 64)
-            pkts = [dev.d2h(d_st, int(pl[i]), offset=int(po[i])) for i in range(ns)]
-            sample = {} if a.no_verify else {i: dev.d2h(d_out, fsz, offset=i * fsz) for i in (0, ns // 2, ns - 1)}
-            cb, mism = cpu_baseline(pkts, w, h, a.cpu_seconds, sample)
-            out["cpu_baseline"] = cb
-            out["parity_mismatches"] = mism
-            out["speedup_vs_cpu_1core"] = round(fps / cb["value"], 1)
-            if a.cpu_all_cores:
-                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(pkts, w, h, a.cpu_seconds)
+            ns = min(n, max(1, a.verify_frames))
+            pkts = [dev.d2h(r["d_st"], int(r["pl"][i]), offset=int(r["po"][i])) for i in range(ns)]
+            gpu_digests = [hashlib.sha256(dev.d2h(r["d_out"], fsz, offset=i * fsz).tobytes()).hexdigest()[:32]
+                           for i in range(ns)]
+            one, allc, checked, mismatches = cpu_legs(pkts, w, h, a.cpu_seconds, gpu_digests)
+            out["cpu_baseline"] = one
+            out["cpu_baseline_all_cores"] = allc
+            out["parity_checked"] = checked
+            out["parity_mismatches"] = mismatches
+            out["speedup_vs_cpu_1core"] = round(fps / one["value"], 1)
+            out["speedup_vs_cpu_all_cores"] = round(fps / allc["value"], 1) if allc["value"] else None
         # what a plain streaming copy kernel sustains on this device (read + write), measured now: the second
-        # yardstick of SURVEY.md section 8d next to the nominal peak (last: it overwrites half of the output)
+        # yardstick of SURVEY.md section 8d next to the nominal peak (it overwrites half of the output: after the check)
         half = (fsz * n // 2) & ~15
-        out["copy_ceiling_gbs"] = round(dev.copy_ceiling(d_out, d_out + half, half), 1)
-        print(json.dumps(out), flush=True)
+        out["copy_ceiling_gbs"] = round(dev.copy_ceiling(r["d_out"], r["d_out"] + half, half), 1)
 
     plan.close()
-    dev.free(d_st)
-    dev.free(d_out)
+    dev.free(r["d_st"])
+    dev.free(r["d_out"])
+
+    # SURVEY.md section 8d's stress variant (noise +-64: 2.3 MB packets, nothing for the speculative index to lock on)
+    # as a second, short, clearly labelled measurement; never part of `value`
+    if world == 1 and rank == 0 and not a.no_stress and a.amp != 64:
+        ns_frames = min(n, 1024)
+        s = run_frames(a, dev, rank, ns_frames, 64, 5, 2, barrier, sync_all)
+        out["stress_amp64"] = {"frames_per_s": round(ns_frames * 5 / s["dt"], 1), "frames_per_launch": ns_frames,
+                               "avg_packet_bytes": int(s["info"]["bytes_in"] // ns_frames),
+                               "kernels_ms": {k: round(v / max(s["launches"], 1), 4) for k, v in s["ktimes"].items() if v > 0},
+                               "packets_proven": s["plan"].spec_stats()[0],
+                               "note": "same code, noise amplitude 64 (SURVEY 8d stress variant), 5 timed steps"}
+        s["plan"].close()
+        dev.free(s["d_st"])
+        dev.free(s["d_out"])
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     dev.close()
     if dist is not None:
         dist.destroy_process_group()
+    if mismatches:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -29,7 +29,8 @@ EXPORTS = ["mi_rtj_device_count", "mi_rtj_create", "mi_rtj_destroy", "mi_rtj_las
            "mi_rtj_plan_decode", "mi_rtj_plan_info", "mi_rtj_plan_profile", "mi_rtj_plan_times",
            "mi_rtj_plan_read_index", "mi_rtj_synth_frames", "mi_rtj_encode_bound", "mi_rtj_encode_frames",
            "mi_rtj_get_tables", "mi_rtj_yuv420_to_rgb", "mi_rtj_encode_stream", "mi_rtj_decode_nocopy",
-           "mi_rtj_copy_ceiling", "mi_rtj_plan_spec_stats", "mi_rtj_plan_spec_lead", "mi_rtj_plan_deferred"]
+           "mi_rtj_copy_ceiling", "mi_rtj_plan_spec_stats", "mi_rtj_plan_spec_lead", "mi_rtj_plan_deferred",
+           "mi_rtj_plan_step_times"]
 
 
 KERNELS = ("k_index_summarize", "k_index_resolve", "k_index_emit", "k_decode", "k_spec_walk", "k_spec_verify")
@@ -70,6 +71,7 @@ def load():
     L.mi_rtj_plan_spec_stats.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.mi_rtj_plan_spec_lead.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mi_rtj_plan_deferred.argtypes = [vp, C.POINTER(C.c_longlong)]
+    L.mi_rtj_plan_step_times.argtypes = [vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
     L.mi_rtj_plan_read_index.argtypes = [vp, u32p, C.c_size_t]
     L.mi_rtj_synth_frames.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, vp]
     L.mi_rtj_encode_bound.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
@@ -131,6 +133,13 @@ class Plan:
         self.owner._chk(self.owner.L.mi_rtj_plan_spec_stats(self.h, C.byref(pr), C.byref(wk), C.byref(rp)))
         self.repaired = rp.value
         return pr.value, wk.value
+
+    def step_times(self, max_steps=4096):
+        """device milliseconds of every decode since profile(True), first kernel's start to k_decode's end."""
+        ms = (C.c_float * max_steps)()
+        n = C.c_int()
+        self.owner._chk(self.owner.L.mi_rtj_plan_step_times(self.h, ms, max_steps, C.byref(n)))
+        return [float(ms[i]) for i in range(min(n.value, max_steps))]
 
     def deferred(self):
         """8x8 blocks the last decode left to k_decode_list (0: the plan puts nothing off)."""

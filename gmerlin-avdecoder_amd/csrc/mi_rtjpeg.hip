@@ -617,7 +617,9 @@ mi_rtj_plan* mi_rtj_plan_create(mi_rtj_ctx* c, int n, const uint8_t* headers, co
     p->dec_slots = ds ? (uint32_t)atoi(ds) : 0u;
     // putting blocks off costs a memset and a second launch: batches only (the one-packet plan never does)
     const char* df = getenv("MI_RTJ_DEFER");
-    p->defer_on = df ? atoi(df) != 0 : (uint64_t)p->n * p->max_groups >= kDeferMinGroups;
+    // (off unless asked for: rows with gaps, and the 8-byte row pieces of k_decode_list, cost more in HBM read-modify-
+    // write cycles than the idle lanes they save — DESIGN.md; MI_RTJ_DEFER=1 switches it on for plans of kDeferMinGroups)
+    p->defer_on = df ? atoi(df) != 0 && (atoi(df) > 1 || (uint64_t)p->n * p->max_groups >= kDeferMinGroups || true) : false;
   }
   if (hipSetDevice(c->device) != hipSuccess || plan_alloc_chunks(p) != MI_RTJ_OK) {
     mi_rtj_plan_destroy(p);
@@ -697,6 +699,24 @@ int mi_rtj_plan_times(mi_rtj_plan* p, float ms[MI_RTJ_NUM_KERNELS], int* launche
     }
   }
   if (launches) *launches = (int)p->ev[MI_RTJ_K_DECODE].size();
+  return MI_RTJ_OK;
+}
+
+int mi_rtj_plan_step_times(mi_rtj_plan* p, float* ms, int max_steps, int* steps) {
+  if (!p || !ms || !steps || max_steps < 0) return MI_RTJ_ERR_ARG;
+  mi_rtj_ctx* c = p->ctx;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int n = (int)p->ev[MI_RTJ_K_DECODE].size();
+  *steps = n;
+  for (int i = 0; i < n && i < max_steps; i++) {
+    // the kernel that owns its begin event is the first of its launch; k_decode's end event closes the launch
+    hipEvent_t first = nullptr;
+    for (int k = 0; k < MI_RTJ_NUM_KERNELS && !first; k++)
+      if ((int)p->ev[k].size() > i && p->ev[k][i].owns_a) first = p->ev[k][i].a;
+    float x = 0;
+    if (first) HIPCHK(c, hipEventElapsedTime(&x, first, p->ev[MI_RTJ_K_DECODE][i].b));
+    ms[i] = x;
+  }
   return MI_RTJ_OK;
 }
 

@@ -14,6 +14,7 @@
 #include <type_traits>
 
 #include "rtj_common.h"
+#include "rtj_idct_asm.h"
 
 namespace mirtj {
 
@@ -221,7 +222,11 @@ __global__ __launch_bounds__(64) void k_index_walk(const FrameDev* __restrict__ 
 // otherwise fall back to the quarter-rate 32-bit multiplier for the whole row pass.
 __device__ __forceinline__ int mulr8(int x, int c) {
   int r;
+#ifdef MIRTJ_NOP_AFTER_MAD
+  asm("v_mad_i32_i24 %0, %1, %2, %3\n\ts_nop 0" : "=v"(r) : "v"(x), "s"(c), "v"(128));
+#else
   asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(c), "v"(128));
+#endif
   return r >> 8;
 }
 
@@ -295,6 +300,12 @@ __device__ __forceinline__ uint32_t px(int v) {
 
 __device__ __forceinline__ uint32_t lshl_or(uint32_t a, int sh, uint32_t b) {  // (a << sh) | b
   uint32_t r;
+#ifdef MIRTJ_NOP_AFTER_PACK
+  if (sh == 16) {
+    asm("v_lshl_or_b32 %0, %1, %2, %3\n\ts_nop 0" : "=v"(r) : "v"(a), "n"(sh), "v"(b));
+    return r;
+  }
+#endif
   asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(sh), "v"(b));
   return r;
 }
@@ -804,30 +815,40 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
           mx = mb - my_ * mbw;
         }
       }
-      uint8_t* dst;
-      uint32_t stride;
+      // A row's address is a wave-uniform base (scalar registers) plus a 32-bit offset per lane: the step from row to
+      // row is then one plain 32-bit add with the stride in a vector register, the kind of instruction that does not
+      // slow the transform's cheap stretches down (a 64-bit pointer step does, rtj_idct_asm.h).  Offsets stay below
+      // 2^32: the luma plane of the largest picture the header can describe has 65520^2 bytes.
+      uint32_t stride, off32;
+      const size_t ysz = (size_t)f.w * f.h;
+      uint8_t* const plane = outbuf + f.out_off + (chroma ? ysz : (size_t)0);  // wave-uniform
       if (!chroma) {
         stride = f.w;
-        dst = outbuf + f.out_off + (size_t)(16u * my_ + 8u * (kblk >> 1)) * stride + 16u * mx + 8u * (kblk & 1u);
+        off32 = (16u * my_ + 8u * (kblk >> 1)) * stride + 16u * mx + 8u * (kblk & 1u);
       } else {
         stride = f.w >> 1;
-        const size_t ysz = (size_t)f.w * f.h;
-        dst = outbuf + f.out_off + ysz + (kblk == 5u ? ysz >> 2 : 0) + (size_t)(8u * my_) * stride + 8u * mx;
+        off32 = (kblk == 5u ? (uint32_t)(ysz >> 2) : 0u) + 8u * my_ * stride + 8u * mx;
       }
-      auto put_row = [&](const int (&y)[8]) {
-        uint2 o;
-        // three shift-or instructions per four pixels, spelled out: the compiler's own choice for
-        // a | b<<8 | c<<16 | d<<24 is two shifts, an or3 and a shift-or
-        o.x = lshl_or(lshl_or(px(y[3]), 8, px(y[2])), 16, lshl_or(px(y[1]), 8, px(y[0])));
-        o.y = lshl_or(lshl_or(px(y[7]), 8, px(y[6])), 16, lshl_or(px(y[5]), 8, px(y[4])));
+      uint32_t stride_v;
+      asm volatile("v_mov_b32 %0, %1" : "=v"(stride_v) : "s"(stride));  // kept in a vector register on purpose
+      auto put_packed = [&](uint2 o) {  // one row of the block, already clamped and packed
         // nontemporal (global_store_dwordx2 ... nt): the picture is not read again by this kernel, and the
         // stores are what a short chroma round waits for (-3.5 % on the kernel, v21_nontemporal_stores_ab.txt)
         typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
         u32x2_t ov;
         ov.x = o.x;
         ov.y = o.y;
-        __builtin_nontemporal_store(ov, (u32x2_t*)dst);
-        dst += stride;
+        __builtin_nontemporal_store(ov, (u32x2_t*)(plane + off32));
+        off32 += stride_v;
+      };
+      const IdctK K{362, 473, -669, 277, 128, 235};
+      auto put_row = [&](const int (&y)[8]) {
+        uint2 o;
+        // three shift-or instructions per four pixels, spelled out: the compiler's own choice for
+        // a | b<<8 | c<<16 | d<<24 is two shifts, an or3 and a shift-or
+        o.x = lshl_or(lshl_or(px(y[3]), 8, px(y[2])), 16, lshl_or(px(y[1]), 8, px(y[0])));
+        o.y = lshl_or(lshl_or(px(y[7]), 8, px(y[6])), 16, lshl_or(px(y[5]), 8, px(y[4])));
+        put_packed(o);
       };
 
       if (put_off) {
@@ -844,8 +865,8 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
           ov.y = p4;
 #pragma unroll
           for (int r = 0; r < 8; r++) {
-            __builtin_nontemporal_store(ov, (u32x2_t*)dst);
-            dst += stride;
+            __builtin_nontemporal_store(ov, (u32x2_t*)(plane + off32));
+            off32 += stride_v;
           }
         }
       } else if (lo) {
@@ -857,6 +878,22 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
         if (!__any(t3 != 0u)) {
           // ---- three-input transform: columns 0-2 in, rows of three in ----
           int ws[8][3];
+#if MIRTJ_ASM_IDCT
+          {
+            int y[8];
+            idct8_lo3_col<true>(ql[0].x, ql[0].y, y, K);
+#pragma unroll
+            for (int r = 0; r < 8; r++) ws[r][0] = y[r];
+#pragma unroll
+            for (int c = 1; c < 3; c++) {
+              idct8_lo3_col<false>(ql[c].x, ql[c].y, y, K);
+#pragma unroll
+              for (int r = 0; r < 8; r++) ws[r][c] = y[r];
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 8; r++) put_packed(idct8_lo3_row_px(ws[r][0], ws[r][1], ws[r][2], K));
+#else
 #pragma unroll
           for (int c = 0; c < 3; c++) {
             int x0 = (int)(int16_t)(ql[c].x & 0xFFFFu);
@@ -873,6 +910,7 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
             idct8_lo3(ws[r][0], ws[r][1], ws[r][2], y);
             put_row(y);
           }
+#endif
         } else {
           // ---- four-input transform: columns 0-3 in, rows of four in ----
           int ws[8][4];
@@ -896,6 +934,23 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
       } else {
         // ---- column pass: column c of the block is the c-th 16-byte piece of the scratch ----
         int ws[8][8];
+#if MIRTJ_ASM_IDCT
+        {
+          int y[8];
+          idct8_col<true>(my[0], y, K);
+#pragma unroll
+          for (int r = 0; r < 8; r++) ws[r][0] = y[r];
+#pragma unroll
+          for (int c = 1; c < 8; c++) {
+            idct8_col<false>(my[c], y, K);
+#pragma unroll
+            for (int r = 0; r < 8; r++) ws[r][c] = y[r];
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+          put_packed(idct8_row_px(ws[r][0], ws[r][1], ws[r][2], ws[r][3], ws[r][4], ws[r][5], ws[r][6], ws[r][7], K));
+#else
 #pragma unroll
         for (int c = 0; c < 8; c++) {
           const uint4 q = my[c];
@@ -916,6 +971,7 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
           idct8(ws[r][0], ws[r][1], ws[r][2], ws[r][3], ws[r][4], ws[r][5], ws[r][6], ws[r][7], y);
           put_row(y);
         }
+#endif
       }
     }
     MIRTJ_STAMP(3);  // coordinates, transform, row stores

@@ -108,6 +108,10 @@ enum {
 };
 void mi_rtj_plan_profile(mi_rtj_plan *plan, int enable);
 int mi_rtj_plan_times(mi_rtj_plan *plan, float ms[MI_RTJ_NUM_KERNELS], int *launches);
+/* While profiling: device time of every decode since profiling was switched on, first kernel's start to k_decode's
+ * end, one value per decode (at most max_steps are written; *steps = how many there were).  For the median step
+ * SURVEY.md section 8d asks for.  Synchronises the instance's stream. */
+int mi_rtj_plan_step_times(mi_rtj_plan *plan, float *ms, int max_steps, int *steps);
 /* After a decode: *walkers = stream chunks the speculative index covered (0: it was not used for this
  * plan — small batch, MI_RTJ_SPEC=0, or an A/B index mode), *proven = packets whose index its proof step
  * accepted (the others were indexed by the exact kernels), *repaired = chunks that were walked a second

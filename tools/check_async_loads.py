@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """Checks the compiled k_decode for the one thing the compiler does not know (csrc/rtj_decode_kernels.h): the
 registers that the hand-issued loads of the group loop are filling must not be touched between the loads and the
-hand-placed `s_waitcnt vmcnt(8)` / `vmcnt(0)` block behind the row stores, every transform variant on the way must
-hold exactly eight stores, and no other vector-memory instruction or compiler-placed vmcnt wait may sit in between.
+hand-placed `s_waitcnt vmcnt(8)` / `vmcnt(0)` block behind the row stores, no other vector-memory instruction than the 8-byte row / mask stores and no compiler-placed vmcnt wait may sit in between.
 
     python tools/check_async_loads.py file.s        (hipcc -save-temps device assembly)
 
@@ -54,13 +53,10 @@ def check(path, kernel="k_decode", fills=4, singles=1):
         if t.startswith("global_load"):
             pending |= regs_of(t.split()[1].rstrip(","))
     errs = []
-    waited = False
-    per_block = []
-    stores = 0
+    # ---- basic blocks between the loads and the hand-placed wait block, with their store counts and successors ----
+    wait_at = None
     for k in range(b1 + 1, len(body)):
-        raw = body[k]
-        t = raw.split(";")[0].strip()
-        if "#ASMSTART" in raw:
+        if "#ASMSTART" in body[k]:
             j = k
             while "#ASMEND" not in body[j]:
                 j += 1
@@ -70,39 +66,63 @@ def check(path, kernel="k_decode", fills=4, singles=1):
                     errs.append(f"line {k}: the wait block has no vmcnt(0) arm for waves that stored nothing")
                 if singles and not any("s_waitcnt vmcnt(9)" in x for x in txt):
                     errs.append(f"line {k}: the wait block has no vmcnt(9) arm for groups that were put off")
-                waited = True
+                wait_at = k
                 break
+    if wait_at is None:
+        return [f"{kernel}: hand-placed wait block not found behind the loads"]
+    blocks_ = []  # (label or None, first line, stores, terminators)
+    cur = {"label": None, "start": b1 + 1, "stores": 0, "succ": [], "fall": True}
+    inasm = False
+    for k in range(b1 + 1, wait_at):
+        raw = body[k]
+        if "#ASMSTART" in raw:
+            inasm = True
+        if "#ASMEND" in raw:
+            inasm = False
+        t = raw.split(";")[0].strip()
         if not t or t.startswith("."):
-            continue
-        if t.endswith(":"):
-            per_block.append(stores)
-            stores = 0
+            if not (t.endswith(":") and t.startswith(".L")):
+                continue
+        if t.endswith(":") and not inasm:
+            blocks_.append(cur)
+            cur = {"label": t[:-1], "start": k, "stores": 0, "succ": [], "fall": True}
             continue
         op = t.split()[0]
-        if op.startswith(("s_cbranch", "s_branch")):
-            per_block.append(stores)
-            stores = 0
-            continue
         if op == "s_waitcnt" and "vmcnt" in t:
             errs.append(f"line {k}: compiler-placed '{t}' while hand-issued loads are pending")
             continue
         if op.startswith("global_store"):
-            stores += 1
+            cur["stores"] += 1
             continue
         if op.startswith(("global_load", "buffer_", "flat_", "global_atomic")):
             errs.append(f"line {k}: vector-memory instruction '{t}' between the loads and their wait")
-        if op == "s_endpgm":
-            break
+        if op.startswith("s_cbranch") and not inasm:
+            cur["succ"].append(t.split()[1])
+            blocks_.append(cur)
+            cur = {"label": None, "start": k + 1, "stores": 0, "succ": [], "fall": True}
+            continue
+        if op == "s_branch" and not inasm:
+            cur["succ"].append(t.split()[1])
+            cur["fall"] = False
+            blocks_.append(cur)
+            cur = {"label": None, "start": k + 1, "stores": 0, "succ": [], "fall": True}
+            continue
         touched = all_vregs(t) & pending
         if touched:
             errs.append(f"line {k}: '{t}' touches pending v{sorted(touched)}")
-    per_block.append(stores)
-    if not waited:
-        errs.append("hand-placed wait block not found behind the loads")
-    nz = sorted(n for n in per_block if n)
-    if nz != [1] * singles + [8] * fills:
-        errs.append(f"{kernel}: stores per basic block between the loads and the wait: {nz}; expected "
-                    f"{[1] * singles + [8] * fills} (the counted waits assume them)")
+    blocks_.append(cur)
+    # How many stores lie on a path is decided by wave-uniform branches this script does not interpret (the three
+    # transform variants, the DC-only fill; the compiler also sinks a variant's last store into a shared block), so
+    # only what can be told from the text is checked: every store is a row store or the mask (8 bytes), and no basic
+    # block holds more than a variant's eight.  That each executed path issues the 8 or 9 stores the counted wait
+    # assumes is what the parity tests show at run time: a wait that is one short hands the parser stale registers.
+    per_block = [b["stores"] for b in blocks_]
+    if max(per_block) > 8 or sum(per_block) < 8:
+        errs.append(f"{kernel}: stores per basic block {sorted(n for n in per_block if n)}")
+    for k in range(b1 + 1, wait_at):
+        t = body[k].split(";")[0].strip()
+        if t.startswith("global_store") and not t.startswith("global_store_dwordx2"):
+            errs.append(f"line {k}: '{t}': only 8-byte stores are expected here")
     return [f"{kernel}: {e}" if not e.startswith(kernel) else e for e in errs]
 
 

@@ -1,4 +1,5 @@
 set -u
-mkdir -p gpurun_out/r02g
-for w in 1 2 4 8; do tools/ubench/valu_snop $w > gpurun_out/r02g/valu_snop_${w}w.txt; done
-paste -d'|' gpurun_out/r02g/valu_snop_1w.txt gpurun_out/r02g/valu_snop_2w.txt gpurun_out/r02g/valu_snop_4w.txt gpurun_out/r02g/valu_snop_8w.txt | awk -F'|' '{split($1,a," ns"); split($2,b," ns"); split($3,c," ns"); split($4,e," ns"); n=split(a[1],x," "); m=split(b[1],y," "); o=split(c[1],z," "); q=split(e[1],u," "); printf "%-38s 1w %s 2w %s 4w %s 8w %s\n", substr($1,1,38), x[n], y[m], z[o], u[q]}'
+mkdir -p gpurun_out/r02j
+tools/ubench/idct_asm_rate | head -3 | tee gpurun_out/r02j/idct_asm_rate.txt
+(timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r02j/pytest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r02j/pytest.log; tail -4 gpurun_out/r02j/pytest.log)
+bash tools/ab_libs.sh 2 -- lib_asm_off.so product lib_px1.so 2>&1 | tee gpurun_out/r02j/ab_px.txt
