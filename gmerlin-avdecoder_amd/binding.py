@@ -30,7 +30,8 @@ EXPORTS = ["mi_rtj_device_count", "mi_rtj_create", "mi_rtj_destroy", "mi_rtj_las
            "mi_rtj_plan_read_index", "mi_rtj_synth_frames", "mi_rtj_encode_bound", "mi_rtj_encode_frames",
            "mi_rtj_get_tables", "mi_rtj_yuv420_to_rgb", "mi_rtj_encode_stream", "mi_rtj_decode_nocopy",
            "mi_rtj_copy_ceiling", "mi_rtj_plan_spec_stats", "mi_rtj_plan_spec_lead", "mi_rtj_plan_deferred",
-           "mi_rtj_plan_step_times"]
+           "mi_rtj_plan_step_times", "mi_rtj_pipe_create", "mi_rtj_pipe_destroy", "mi_rtj_pipe_room",
+           "mi_rtj_pipe_pending", "mi_rtj_pipe_submit", "mi_rtj_pipe_next", "mi_rtj_pipe_peek_tag", "mi_rtj_pipe_flush"]
 
 
 KERNELS = ("k_index_summarize", "k_index_resolve", "k_index_emit", "k_decode", "k_spec_walk", "k_spec_verify")
@@ -72,6 +73,17 @@ def load():
     L.mi_rtj_plan_spec_lead.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mi_rtj_plan_deferred.argtypes = [vp, C.POINTER(C.c_longlong)]
     L.mi_rtj_plan_step_times.argtypes = [vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
+    L.mi_rtj_pipe_create.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.mi_rtj_pipe_create.restype = vp
+    L.mi_rtj_pipe_destroy.argtypes = [vp]
+    L.mi_rtj_pipe_destroy.restype = None
+    L.mi_rtj_pipe_room.argtypes = [vp]
+    L.mi_rtj_pipe_pending.argtypes = [vp]
+    L.mi_rtj_pipe_submit.argtypes = [vp, u8p, C.c_size_t, C.c_uint64]
+    L.mi_rtj_pipe_next.argtypes = [vp, C.POINTER(u8p), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                   C.POINTER(C.c_uint64)]
+    L.mi_rtj_pipe_peek_tag.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.mi_rtj_pipe_flush.argtypes = [vp]
     L.mi_rtj_plan_read_index.argtypes = [vp, u32p, C.c_size_t]
     L.mi_rtj_synth_frames.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, vp]
     L.mi_rtj_encode_bound.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]

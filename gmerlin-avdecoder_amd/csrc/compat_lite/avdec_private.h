@@ -56,8 +56,12 @@ typedef struct gavl_dictionary_s { char format[64]; } gavl_dictionary_t;
 typedef struct bgav_stream_s bgav_stream_t;
 typedef struct bgav_video_decoder_s bgav_video_decoder_t;
 
+#define GAVL_TIME_UNDEFINED ((int64_t)0x8000000000000000LL)
+#define MI_RTJ_HAVE_OUT_TIME 1 /* the real bgav_stream_t has it too (include/avdec_private.h; lib/video.c:295) */
+
 struct bgav_stream_s {
   void *decoder_priv;
+  int64_t out_time; /* timestamp the next picture is expected to have (lib/video.c:295,527-528,607) */
   gavl_video_frame_t *vframe; /* set by a decoder that owns its output frame: nocopy mode (lib/video.c:420-429) */
   uint32_t fourcc;
   gavl_dictionary_t *m;    /* stream metadata */

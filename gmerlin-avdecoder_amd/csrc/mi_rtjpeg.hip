@@ -95,8 +95,38 @@ struct mi_rtj_plan {
   unsigned long long* d_defer = nullptr;   // [k_decode waves][kDecIters]: lanes whose blocks k_decode put off
   size_t cap_defer = 0, defer_words = 0;   // allocated / used by the last launch
   bool defer_on = true;                    // MI_RTJ_DEFER=0 switches the putting-off off (A/B)
+  const uint8_t* prev_pic = nullptr;       // sessions: where unchanged blocks of this launch are copied from
   std::vector<Timed> ev[MI_RTJ_NUM_KERNELS];  // one pair per launch while profiling
   int launches = 0;
+};
+
+// One packet in flight of a pipelined session (mi_rtj_pipe_*): its own pinned staging, device packet, device
+// picture, pinned host picture and one-frame plan, so that the copy in of packet i+1, the kernels of packet i and the
+// copy out of picture i-1 run side by side on three streams.
+struct PipeSlot {
+  mi_rtj_plan* plan = nullptr;
+  uint8_t* h_stage = nullptr;  // pinned: FrameDev (64 bytes), then the packet
+  uint8_t* d_stage = nullptr;
+  size_t stage_cap = 0;
+  uint8_t* d_pic = nullptr;    // this packet's picture on the device (starts as a copy of its predecessor's)
+  uint8_t* h_pic = nullptr;    // pinned host picture handed to the caller
+  size_t pic_cap = 0;
+  hipEvent_t e_in = nullptr, e_dec = nullptr, e_out = nullptr;
+  uint64_t tag = 0;
+  int w = 0, h = 0;
+};
+
+struct mi_rtj_pipe {
+  mi_rtj_ctx* ctx = nullptr;
+  int depth = 0;
+  int max_w = 0, max_h = 0;   // the stream's coded size: packets that announce more are refused
+  std::vector<PipeSlot> slot;
+  int head = 0, count = 0;    // oldest packet in flight, packets in flight
+  int lent = -1;              // slot whose host picture the caller is looking at (until the next mi_rtj_pipe_next)
+  const uint8_t* prev_pic = nullptr;  // device picture of the packet submitted last (what 0xFF blocks keep)
+  size_t prev_bytes = 0;
+  hipStream_t s_in = nullptr, s_out = nullptr;  // kernels run on the instance's stream
+  uint64_t submitted = 0, returned = 0;
 };
 
 namespace {
@@ -414,7 +444,7 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
     HIPCHK(c, hipMemsetAsync(defer, 0, words * sizeof(unsigned long long), c->stream));
   }
   hipLaunchKernelGGL(k_decode, dim3(dslots * 3u, p->n), dim3(kDecThreads), 0, c->stream, p->d_frames, st, c->d_lut,
-                     p->d_blkoff, (uint8_t*)d_out, defer);
+                     p->d_blkoff, (uint8_t*)d_out, defer, p->prev_pic);
   if (defer)
     hipLaunchKernelGGL(k_decode_list, dim3(dslots * 3u, p->n), dim3(kDecThreads), 0, c->stream, p->d_frames, st, c->d_lut,
                        p->d_blkoff, (uint8_t*)d_out, defer);
@@ -914,6 +944,216 @@ int mi_rtj_decode_nocopy(mi_rtj_ctx* c, const uint8_t* pkt, size_t len, const ui
   planes[2] = c->h_frame + ysz + ysz / 4;
   strides[0] = (int)f.w;
   strides[1] = strides[2] = (int)f.w / 2;
+  return MI_RTJ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Pipelined session: the decoder a frame-owning plugin instance reads ahead with (lib/video.c:420-441 nocopy source,
+// lib/video_v4l2_m2m.c:43-131 as the in-tree precedent of a decoder with packets in flight).
+// ---------------------------------------------------------------------------------------------------------------
+mi_rtj_pipe* mi_rtj_pipe_create(mi_rtj_ctx* c, int depth, int max_w, int max_h) {
+  if (!c || depth < 2 || depth > 64 || max_w < 0 || max_h < 0) {
+    fail(c, MI_RTJ_ERR_ARG, "mi_rtj_pipe_create: bad argument (depth 2..64)");
+    return nullptr;
+  }
+  if (hipSetDevice(c->device) != hipSuccess) {
+    fail(c, MI_RTJ_ERR_HIP, "mi_rtj_pipe_create: hipSetDevice failed");
+    return nullptr;
+  }
+  mi_rtj_pipe* q = new mi_rtj_pipe();
+  q->ctx = c;
+  q->depth = depth;
+  q->max_w = max_w;
+  q->max_h = max_h;
+  q->slot.resize(depth);
+  bool ok = hipStreamCreateWithFlags(&q->s_in, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags(&q->s_out, hipStreamNonBlocking) == hipSuccess;
+  const char* mode = getenv("MI_RTJ_INDEX");
+  const char* em = getenv("MI_RTJ_EMIT");
+  for (auto& sl : q->slot) {
+    sl.plan = new mi_rtj_plan();
+    sl.plan->ctx = c;
+    sl.plan->n = 1;
+    sl.plan->defer_on = false;
+    sl.plan->spec_mode = 0;  // one packet per launch: the exact index (a lone walker takes longer than all of it)
+    sl.plan->serial_index = mode && strcmp(mode, "serial") == 0;
+    sl.plan->emit_walk = em && strcmp(em, "walk") == 0;
+    sl.plan->h_frames.resize(1);
+    ok = ok && hipEventCreateWithFlags(&sl.e_in, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&sl.e_dec, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&sl.e_out, hipEventDisableTiming) == hipSuccess;
+  }
+  if (!ok) {
+    fail(c, MI_RTJ_ERR_HIP, "mi_rtj_pipe_create: cannot create streams / events");
+    mi_rtj_pipe_destroy(q);
+    return nullptr;
+  }
+  return q;
+}
+
+void mi_rtj_pipe_destroy(mi_rtj_pipe* q) {
+  if (!q) return;
+  mi_rtj_ctx* c = q->ctx;
+  (void)hipSetDevice(c->device);
+  if (q->s_in) (void)hipStreamSynchronize(q->s_in);
+  (void)hipStreamSynchronize(c->stream);
+  if (q->s_out) (void)hipStreamSynchronize(q->s_out);
+  for (auto& sl : q->slot) {
+    if (sl.plan) {
+      sl.plan->d_frames = nullptr;  // points into d_stage, not owned by the plan
+      mi_rtj_plan_destroy(sl.plan);
+    }
+    if (sl.h_stage) (void)hipHostFree(sl.h_stage);
+    if (sl.d_stage) (void)hipFree(sl.d_stage);
+    if (sl.d_pic) (void)hipFree(sl.d_pic);
+    if (sl.h_pic) (void)hipHostFree(sl.h_pic);
+    if (sl.e_in) (void)hipEventDestroy(sl.e_in);
+    if (sl.e_dec) (void)hipEventDestroy(sl.e_dec);
+    if (sl.e_out) (void)hipEventDestroy(sl.e_out);
+  }
+  if (q->s_in) (void)hipStreamDestroy(q->s_in);
+  if (q->s_out) (void)hipStreamDestroy(q->s_out);
+  delete q;
+}
+
+int mi_rtj_pipe_room(const mi_rtj_pipe* q) {
+  if (!q) return 0;
+  return q->depth - q->count - (q->lent >= 0 ? 1 : 0);
+}
+
+int mi_rtj_pipe_pending(const mi_rtj_pipe* q) { return q ? q->count : 0; }
+
+int mi_rtj_pipe_submit(mi_rtj_pipe* q, const uint8_t* pkt, size_t len, uint64_t tag) {
+  if (!q || !pkt) return fail(q ? q->ctx : nullptr, MI_RTJ_ERR_ARG, "mi_rtj_pipe_submit: NULL argument");
+  mi_rtj_ctx* c = q->ctx;
+  if (len < MI_RTJ_HEADER_SIZE) return fail(c, MI_RTJ_ERR_ARG, "mi_rtj_pipe_submit: packet shorter than its %d-byte header", MI_RTJ_HEADER_SIZE);
+  if (mi_rtj_pipe_room(q) <= 0) return fail(c, MI_RTJ_ERR_ARG, "mi_rtj_pipe_submit: %d packets in flight already (take a picture first)", q->count);
+  HIPCHK(c, hipSetDevice(c->device));
+  // the header against the stream's size BEFORE anything is allocated for it (a 65520 x 65520 header would ask for
+  // gigabytes; the reference's frame has the container's size whatever the packet says, lib/video_rtjpeg.c:50-54)
+  {
+    const int hw = pkt[6] | (pkt[7] << 8), hh = pkt[8] | (pkt[9] << 8);
+    if (q->max_w && q->max_h && (hw != q->max_w || hh != q->max_h))
+      return fail(c, MI_RTJ_ERR_GEOMETRY, "packet header %dx%d does not match the stream's coded size %dx%d", hw, hh, q->max_w, q->max_h);
+  }
+  // the slots form a ring: the lent one (if any) sits just before head, then head .. head+count-1, then the free ones
+  PipeSlot& sl = q->slot[(q->head + q->count) % q->depth];
+  mi_rtj_plan* p = sl.plan;
+  const int rc = fill_frame(c, pkt, 0, (uint32_t)len, 0, 0, &p->h_frames[0]);
+  if (rc != MI_RTJ_OK) return rc;
+  FrameDev& f = p->h_frames[0];
+  const size_t fsz = (size_t)f.w * f.h * 3 / 2;
+  if (fsz > sl.pic_cap) {
+    if (sl.d_pic) (void)hipFree(sl.d_pic);
+    if (sl.h_pic) (void)hipHostFree(sl.h_pic);
+    sl.d_pic = sl.h_pic = nullptr;
+    sl.pic_cap = 0;
+    HIPCHK(c, hipMalloc((void**)&sl.d_pic, fsz + kAllocPad));
+    HIPCHK(c, hipMemsetAsync(sl.d_pic, 0, fsz + kAllocPad, c->stream));
+    HIPCHK(c, hipHostMalloc((void**)&sl.h_pic, fsz, hipHostMallocDefault));
+    sl.pic_cap = fsz;
+  }
+  const size_t need = sizeof(FrameDev) + len + kAllocPad;
+  if (need > sl.stage_cap) {
+    if (sl.h_stage) (void)hipHostFree(sl.h_stage);
+    if (sl.d_stage) (void)hipFree(sl.d_stage);
+    sl.h_stage = sl.d_stage = nullptr;
+    sl.stage_cap = 0;
+    HIPCHK(c, hipHostMalloc((void**)&sl.h_stage, need * 2, hipHostMallocDefault));
+    HIPCHK(c, hipMalloc((void**)&sl.d_stage, need * 2));
+    sl.stage_cap = need * 2;
+  }
+  const uint64_t nidx = (((uint64_t)f.nmb * 6 + 1) + 63) & ~63ull;
+  if (nidx > p->n_index) {
+    if (p->d_blkoff) (void)hipFree(p->d_blkoff);
+    p->d_blkoff = nullptr;
+    p->n_index = 0;
+    HIPCHK(c, hipMalloc((void**)&p->d_blkoff, sizeof(uint32_t) * nidx));
+    p->n_index = nidx;
+  }
+  p->n_blocks = (uint64_t)f.nmb * 6;
+  p->max_groups = (f.nmb + kMbPerGroup - 1) / kMbPerGroup;
+  {
+    const int rc2 = plan_alloc_chunks(p);  // sets the chunk bases in the descriptor; allocates only when it grows
+    if (rc2 != MI_RTJ_OK) return rc2;
+  }
+  // descriptor and packet travel together: one copy in, on its own stream
+  f.data_off = sizeof(FrameDev) + MI_RTJ_HEADER_SIZE;
+  memcpy(sl.h_stage, &f, sizeof(FrameDev));
+  memcpy(sl.h_stage + sizeof(FrameDev), pkt, len);
+  p->d_frames = (FrameDev*)sl.d_stage;
+  // (a stream of its own: with the copy in queued between the kernels of successive packets the session ran at
+  // 6-10 K pictures per second instead of 12 K, and the deeper the pipeline the slower — profiles/r02/e2e_*.txt)
+  HIPCHK(c, hipMemcpyAsync(sl.d_stage, sl.h_stage, sizeof(FrameDev) + len, hipMemcpyHostToDevice, q->s_in));
+  HIPCHK(c, hipEventRecord(sl.e_in, q->s_in));
+  HIPCHK(c, hipStreamWaitEvent(c->stream, sl.e_in, 0));
+  // kernels, in submission order on the instance's stream: the picture starts as its predecessor's (0xFF blocks
+  // keep what was there, lib/RTjpeg.c:2704), then the packet is decoded over it
+  // unchanged (0xFF) blocks: k_decode fetches them from the predecessor's picture (a packet of another size has no
+  // predecessor in that sense: its unchanged blocks keep what the slot's buffer holds, zeros at first)
+  p->prev_pic = q->prev_pic && q->prev_bytes == fsz && q->prev_pic != sl.d_pic ? q->prev_pic : nullptr;
+  const int rc3 = plan_launch(p, sl.d_stage, sl.d_pic);
+  if (rc3 != MI_RTJ_OK) return rc3;
+  HIPCHK(c, hipEventRecord(sl.e_dec, c->stream));
+  // copy out, on the third stream
+  HIPCHK(c, hipStreamWaitEvent(q->s_out, sl.e_dec, 0));
+  HIPCHK(c, hipMemcpyAsync(sl.h_pic, sl.d_pic, fsz, hipMemcpyDeviceToHost, q->s_out));
+  HIPCHK(c, hipEventRecord(sl.e_out, q->s_out));
+  sl.tag = tag;
+  sl.w = (int)f.w;
+  sl.h = (int)f.h;
+  q->prev_pic = sl.d_pic;
+  q->prev_bytes = fsz;
+  q->count++;
+  q->submitted++;
+  return MI_RTJ_OK;
+}
+
+int mi_rtj_pipe_next(mi_rtj_pipe* q, const uint8_t* planes[3], int strides[3], int* w, int* h, uint64_t* tag) {
+  if (!q) return MI_RTJ_ERR_ARG;
+  mi_rtj_ctx* c = q->ctx;
+  q->lent = -1;  // the picture handed out before is the caller's no longer
+  if (q->count == 0) return fail(c, MI_RTJ_ERR_ARG, "mi_rtj_pipe_next: nothing in flight");
+  HIPCHK(c, hipSetDevice(c->device));
+  PipeSlot& sl = q->slot[q->head];
+  HIPCHK(c, hipEventSynchronize(sl.e_out));
+  if (planes) {
+    const size_t ysz = (size_t)sl.w * sl.h;
+    planes[0] = sl.h_pic;
+    planes[1] = sl.h_pic + ysz;
+    planes[2] = sl.h_pic + ysz + ysz / 4;
+    q->lent = q->head;
+  }
+  if (strides) {
+    strides[0] = sl.w;
+    strides[1] = strides[2] = sl.w / 2;
+  }
+  if (w) *w = sl.w;
+  if (h) *h = sl.h;
+  if (tag) *tag = sl.tag;
+  q->head = (q->head + 1) % q->depth;
+  q->count--;
+  q->returned++;
+  return MI_RTJ_OK;
+}
+
+int mi_rtj_pipe_peek_tag(const mi_rtj_pipe* q, uint64_t* tag) {
+  if (!q || !tag || q->count == 0) return MI_RTJ_ERR_ARG;
+  *tag = q->slot[q->head].tag;
+  return MI_RTJ_OK;
+}
+
+int mi_rtj_pipe_flush(mi_rtj_pipe* q) {
+  if (!q) return MI_RTJ_ERR_ARG;
+  mi_rtj_ctx* c = q->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  // work in flight cannot be recalled; it is waited for and forgotten (a seek is rare, a frame takes microseconds)
+  HIPCHK(c, hipStreamSynchronize(q->s_in));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipStreamSynchronize(q->s_out));
+  q->head = (q->head + q->count) % q->depth;
+  q->count = 0;
+  q->lent = -1;
   return MI_RTJ_OK;
 }
 

@@ -473,7 +473,7 @@ template <bool kList>
 __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const FrameDev* __restrict__ frames,
                                             const uint8_t* __restrict__ stream, const QTab* __restrict__ lut,
                                             const uint32_t* __restrict__ blkoff, uint8_t* __restrict__ outbuf,
-                                            unsigned long long* __restrict__ defer) {
+                                            unsigned long long* __restrict__ defer, const uint8_t* __restrict__ prev) {
   uint32_t* s_tab = s_lds + kCoefWords;  // per zig-zag slot: (dequantiser << 16) | scratch byte offset
 
   const FrameDev f = frames[blockIdx.y];
@@ -620,6 +620,31 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
   // they are pending) and waited for by hand; `next_bytes` and `pos_nn` must not be read before that wait.
   // (Round 1 loaded the offset at the top of the next iteration and the compiler waited with vmcnt(0) at the loop
   // end: every wave sat out the latency of its row stores once per group.)
+  // where a block's eight rows go: a wave-uniform plane base (scalar registers) plus a 32-bit offset per lane, so that
+  // the step from row to row is one plain 32-bit add with the stride in a vector register — the kind of instruction
+  // that does not slow the transform's cheap stretches down (a 64-bit pointer step does, rtj_idct_asm.h).  Offsets
+  // stay below 2^32: the luma plane of the largest picture the header can describe has 65520^2 bytes.
+  const size_t ysz = (size_t)f.w * f.h;
+  const size_t plane_off = f.out_off + (chroma ? ysz : (size_t)0);  // wave-uniform
+  const uint32_t stride = chroma ? f.w >> 1 : f.w;
+  auto block_offset = [&](uint32_t grp, uint32_t dmb, uint32_t kblk, uint32_t mb) -> uint32_t {
+    // macroblock coordinates without a per-lane division: one scalar division for the group's
+    // first macroblock, then at most one row wrap per lane when rows are at least a group wide
+    uint32_t mx, my_;
+    const uint32_t mbw = f.mbw, mb0 = grp * (uint32_t)kMbPerGroup;
+    const uint32_t gy = mb0 / mbw, gx = mb0 - gy * mbw;  // uniform in k_decode
+    if (!kList && mbw >= (uint32_t)kMbPerGroup) {
+      const bool wrap = gx + dmb >= mbw;
+      mx = wrap ? gx + dmb - mbw : gx + dmb;
+      my_ = wrap ? gy + 1u : gy;
+    } else {
+      my_ = mb / mbw;
+      mx = mb - my_ * mbw;
+    }
+    return chroma ? (kblk == 5u ? (uint32_t)(ysz >> 2) : 0u) + 8u * my_ * stride + 8u * mx
+                  : (16u * my_ + 8u * (kblk >> 1)) * stride + 16u * mx + 8u * (kblk & 1u);
+  };
+
 #ifdef MIRTJ_STAMPS
   unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
 #endif
@@ -747,6 +772,21 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
       }
     }
 
+    // ---- sessions with packets in flight give every packet a picture of its own: its unchanged (0xFF) blocks are
+    // then fetched from the previous packet's picture (`prev`), which is what "left as it was" means there ----
+    if (prev) {  // wave-uniform
+      const bool keep = valid && !live_any;
+      if (keep) {
+        uint32_t o = block_offset(grp, dmb, kblk, mb);
+        const uint8_t* src = prev + plane_off - f.out_off;  // the previous picture has the same layout, at its own base
+        uint8_t* const dstp = outbuf + plane_off;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          *(uint2*)(dstp + o) = *(const uint2*)(src + o);
+          o += stride;
+        }
+      }
+    }
     MIRTJ_STAMP(1);  // classification + parse
     // ---- request the next group's stream bytes and the block offset of the group after it: they arrive while
     // this group is transformed ----
@@ -800,35 +840,8 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
 
     MIRTJ_STAMP(2);  // look-ahead loads issued, low-4x4 test
     if (live_any) {
-      // macroblock coordinates without a per-lane division: one scalar division for the group's
-      // first macroblock, then at most one row wrap per lane when rows are at least a group wide
-      uint32_t mx, my_;
-      {
-        const uint32_t mbw = f.mbw, mb0 = grp * (uint32_t)kMbPerGroup;
-        const uint32_t gy = mb0 / mbw, gx = mb0 - gy * mbw;  // uniform
-        if (!kList && mbw >= (uint32_t)kMbPerGroup) {
-          const bool wrap = gx + dmb >= mbw;
-          mx = wrap ? gx + dmb - mbw : gx + dmb;
-          my_ = wrap ? gy + 1u : gy;
-        } else {
-          my_ = mb / mbw;
-          mx = mb - my_ * mbw;
-        }
-      }
-      // A row's address is a wave-uniform base (scalar registers) plus a 32-bit offset per lane: the step from row to
-      // row is then one plain 32-bit add with the stride in a vector register, the kind of instruction that does not
-      // slow the transform's cheap stretches down (a 64-bit pointer step does, rtj_idct_asm.h).  Offsets stay below
-      // 2^32: the luma plane of the largest picture the header can describe has 65520^2 bytes.
-      uint32_t stride, off32;
-      const size_t ysz = (size_t)f.w * f.h;
-      uint8_t* const plane = outbuf + f.out_off + (chroma ? ysz : (size_t)0);  // wave-uniform
-      if (!chroma) {
-        stride = f.w;
-        off32 = (16u * my_ + 8u * (kblk >> 1)) * stride + 16u * mx + 8u * (kblk & 1u);
-      } else {
-        stride = f.w >> 1;
-        off32 = (kblk == 5u ? (uint32_t)(ysz >> 2) : 0u) + 8u * my_ * stride + 8u * mx;
-      }
+      uint32_t off32 = block_offset(grp, dmb, kblk, mb);
+      uint8_t* const plane = outbuf + plane_off;
       uint32_t stride_v;
       asm volatile("v_mov_b32 %0, %1" : "=v"(stride_v) : "s"(stride));  // kept in a vector register on purpose
       auto put_packed = [&](uint2 o) {  // one row of the block, already clamped and packed
@@ -1025,14 +1038,17 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
 }
 
 // k_decode: see above.  `defer` = nullptr: no group's blocks are put off (every live block is transformed here).
+// `prev` = nullptr: unchanged (0xFF) blocks keep what the output buffer holds; else they are copied from the picture
+// at `prev` (same layout as the output buffer: frame i of the plan at prev + its out_off).
 __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const FrameDev* __restrict__ frames,
                                                          const uint8_t* __restrict__ stream,
                                                          const QTab* __restrict__ lut,
                                                          const uint32_t* __restrict__ blkoff,
                                                          uint8_t* __restrict__ outbuf,
-                                                         unsigned long long* __restrict__ defer) {
+                                                         unsigned long long* __restrict__ defer,
+                                                         const uint8_t* __restrict__ prev) {
   __shared__ __attribute__((aligned(16))) uint32_t s_lds[kDecLdsWords];
-  decode_wave<false>(s_lds, frames, stream, lut, blkoff, outbuf, defer);
+  decode_wave<false>(s_lds, frames, stream, lut, blkoff, outbuf, defer, prev);
 }
 
 // k_decode_list: same grid; the wave (slot, part, frame) takes the blocks its k_decode twin put off, 64 per round —
@@ -1045,7 +1061,7 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode_list(co
                                                               uint8_t* __restrict__ outbuf,
                                                               unsigned long long* __restrict__ defer) {
   __shared__ __attribute__((aligned(16))) uint32_t s_lds[kDecLdsWords + kDecListWords];
-  decode_wave<true>(s_lds, frames, stream, lut, blkoff, outbuf, defer);
+  decode_wave<true>(s_lds, frames, stream, lut, blkoff, outbuf, defer, nullptr);
 }
 
 // set bits of a word array (mi_rtj_plan_deferred: blocks put off by the last k_decode)

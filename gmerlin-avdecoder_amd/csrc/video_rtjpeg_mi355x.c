@@ -21,13 +21,33 @@
 
 #define LOG_DOMAIN "video_rtjpeg_mi355x"
 
+/* bgav_stream_t::out_time (include/avdec_private.h) tells a read-ahead decoder which pictures became stale when the
+ * library skipped packets by itself; -DMI_RTJ_NO_OUT_TIME for a tree whose stream struct lacks it */
+#if !defined(MI_RTJ_NO_OUT_TIME) && !defined(MI_RTJ_HAVE_OUT_TIME)
+#define MI_RTJ_HAVE_OUT_TIME 1
+#endif
+
 #define BLOCK_SIZE 16
 #define PADD(x) ((((x) + BLOCK_SIZE - 1) / BLOCK_SIZE) * BLOCK_SIZE)
+
+#ifdef MI_RTJ_PIPELINE /* the read-ahead decoder is a frame-owning one */
+#ifndef MI_RTJ_NOCOPY
+#define MI_RTJ_NOCOPY 1
+#endif
+#define MI_RTJ_MAX_DEPTH 64
+#endif
 
 typedef struct {
   mi_rtj_ctx *ctx; /* owns the persistent device picture: the role of priv->frame + priv->rtjpeg */
 #ifdef MI_RTJ_NOCOPY
   gavl_video_frame_t *vframe; /* plane pointers into the instance's pinned host picture */
+#endif
+#ifdef MI_RTJ_PIPELINE
+  mi_rtj_pipe *pipe;                      /* packets in flight (include/mi_rtjpeg.h, "pipelined session") */
+  bgav_packet_t meta[MI_RTJ_MAX_DEPTH];   /* pts, duration, timecode... of the packets in flight, by tag % depth */
+  uint64_t next_tag;
+  int depth;
+  int eof;                                /* the packet source ran dry: hand out what is in flight, then EOF */
 #endif
 } rtjpeg_hip_priv_t;
 
@@ -62,9 +82,128 @@ static int init_rtjpeg_hip(bgav_stream_t *s) {
   priv->vframe = gavl_video_frame_create(NULL);
   s->vframe = priv->vframe;
 #endif
+#ifdef MI_RTJ_PIPELINE
+  {
+    /* packets in flight: MI_RTJ_DEPTH (default 4: 12.0 K pictures per second at 1080p, 11.6 K with 6, 11.2 K with 8; BGAV_OPT_VIDEOBUFFER is what lib/video_v4l2_m2m.c:66 reads for
+     * the same purpose — an instance built inside the tree can take it from s->opt instead) */
+    const char *d = getenv("MI_RTJ_DEPTH");
+    priv->depth = d ? atoi(d) : 4;
+    if (priv->depth < 2) priv->depth = 2;
+    if (priv->depth > MI_RTJ_MAX_DEPTH) priv->depth = MI_RTJ_MAX_DEPTH;
+    priv->pipe = mi_rtj_pipe_create(priv->ctx, priv->depth, s->data.video.format->frame_width,
+                                    s->data.video.format->frame_height);
+    if (!priv->pipe) {
+      gavl_log(GAVL_LOG_ERROR, LOG_DOMAIN, "Cannot set up the decoder pipeline: %s", mi_rtj_last_error(priv->ctx));
+      gavl_video_frame_null(priv->vframe);
+      gavl_video_frame_destroy(priv->vframe);
+      s->vframe = NULL;
+      mi_rtj_destroy(priv->ctx);
+      free(priv);
+      s->decoder_priv = NULL;
+      return 0;
+    }
+  }
+#endif
   return 1;
 }
 
+#ifdef MI_RTJ_PIPELINE
+/* Read ahead: packets are pulled and queued while the pipeline has room.  A packet's bytes are copied by
+ * mi_rtj_pipe_submit before bgav_stream_done_packet_read (they are only valid until the next get,
+ * lib/stream.c:538-601); what bgav_set_video_frame_from_packet needs later is kept under the packet's tag.
+ * Returns the status of the last get (OK while the source delivers). */
+static gavl_source_status_t fill_pipeline(bgav_stream_t *s) {
+  rtjpeg_hip_priv_t *priv = s->decoder_priv;
+  gavl_source_status_t st = GAVL_SOURCE_OK;
+  while (!priv->eof && mi_rtj_pipe_room(priv->pipe) > 0) {
+    bgav_packet_t *p = NULL;
+    if ((st = bgav_stream_get_packet_read(s, &p)) != GAVL_SOURCE_OK) {
+      if (st == GAVL_SOURCE_EOF) priv->eof = 1;
+      break;
+    }
+    priv->meta[priv->next_tag % (uint64_t)priv->depth] = *p;
+    priv->meta[priv->next_tag % (uint64_t)priv->depth].buf.buf = NULL; /* the bytes are not ours to keep */
+    if (mi_rtj_pipe_submit(priv->pipe, p->buf.buf, (size_t)p->buf.len, priv->next_tag) != MI_RTJ_OK) {
+      gavl_log(GAVL_LOG_ERROR, LOG_DOMAIN, "Decoding failed: %s", mi_rtj_last_error(priv->ctx));
+      bgav_stream_done_packet_read(s, p);
+      priv->eof = 1; /* errors are EOF + a log line; pictures already in flight are still handed out */
+      return GAVL_SOURCE_EOF;
+    }
+    priv->next_tag++;
+    bgav_stream_done_packet_read(s, p);
+  }
+  return st;
+}
+
+static gavl_source_status_t decode_rtjpeg_pipe(bgav_stream_t *s, gavl_video_frame_t *f) {
+  rtjpeg_hip_priv_t *priv = s->decoder_priv;
+  const uint8_t *planes[3];
+  int strides[3], i;
+  uint64_t tag;
+  gavl_source_status_t st;
+  (void)f; /* always NULL for a frame-owning decoder (lib/video.c:262) */
+  for (;;) {
+    st = fill_pipeline(s);
+    if (mi_rtj_pipe_pending(priv->pipe) == 0) return st == GAVL_SOURCE_OK ? GAVL_SOURCE_EOF : st; /* EOF or AGAIN */
+#ifdef MI_RTJ_HAVE_OUT_TIME
+    /* the library skips packets of intra-only streams by itself (bgav_video_skipto, lib/video.c:596-612) and sets
+     * s->out_time to the first packet it kept: pictures of packets read ahead before that are stale */
+    if (mi_rtj_pipe_peek_tag(priv->pipe, &tag) == MI_RTJ_OK) {
+      const bgav_packet_t *m = &priv->meta[tag % (uint64_t)priv->depth];
+      if (s->out_time != GAVL_TIME_UNDEFINED && m->duration > 0 && m->pts + m->duration <= s->out_time) {
+        mi_rtj_pipe_next(priv->pipe, NULL, NULL, NULL, NULL, NULL);
+        continue;
+      }
+    }
+#endif
+    break;
+  }
+  if (mi_rtj_pipe_next(priv->pipe, planes, strides, NULL, NULL, &tag) != MI_RTJ_OK) {
+    gavl_log(GAVL_LOG_ERROR, LOG_DOMAIN, "Decoding failed: %s", mi_rtj_last_error(priv->ctx));
+    return GAVL_SOURCE_EOF;
+  }
+  for (i = 0; i < 3; i++) {
+    priv->vframe->planes[i] = (uint8_t *)planes[i];
+    priv->vframe->strides[i] = strides[i];
+  }
+  bgav_set_video_frame_from_packet(&priv->meta[tag % (uint64_t)priv->depth], priv->vframe);
+  fill_pipeline(s); /* keep the device busy while the application looks at this picture */
+  return GAVL_SOURCE_OK;
+}
+
+/* .resync (include/avdec_private.h:110; called after a seek, lib/video.c:561-562): everything read ahead belongs
+ * to the old position */
+static void resync_rtjpeg_pipe(bgav_stream_t *s) {
+  rtjpeg_hip_priv_t *priv = s->decoder_priv;
+  mi_rtj_pipe_flush(priv->pipe);
+  priv->eof = 0;
+}
+
+/* .skipto (include/avdec_private.h:112-115: "only needed for decoders which are not synchronous"; called by
+ * bgav_video_skipto for streams with keyframes, lib/video.c:633-634): drop pictures until the next one ends after
+ * `dest`; that one stays in flight for the next decode.  Every packet still goes through the decoder, as 0xFF blocks
+ * need their predecessors. */
+static int skipto_rtjpeg_pipe(bgav_stream_t *s, int64_t dest) {
+  rtjpeg_hip_priv_t *priv = s->decoder_priv;
+  for (;;) {
+    uint64_t tag;
+    const bgav_packet_t *m;
+    gavl_source_status_t st = fill_pipeline(s);
+    if (mi_rtj_pipe_pending(priv->pipe) == 0) return st == GAVL_SOURCE_AGAIN ? 1 : 0;
+    mi_rtj_pipe_peek_tag(priv->pipe, &tag);
+    m = &priv->meta[tag % (uint64_t)priv->depth];
+    if (m->pts + m->duration > dest) {
+#ifdef MI_RTJ_HAVE_OUT_TIME
+      s->out_time = m->pts;
+#endif
+      return 1;
+    }
+    mi_rtj_pipe_next(priv->pipe, NULL, NULL, NULL, NULL, NULL);
+  }
+}
+#endif /* MI_RTJ_PIPELINE */
+
+#ifndef MI_RTJ_PIPELINE
 static gavl_source_status_t decode_rtjpeg_hip(bgav_stream_t *s, gavl_video_frame_t *f) {
   rtjpeg_hip_priv_t *priv = s->decoder_priv;
   bgav_packet_t *p = NULL;
@@ -81,6 +220,18 @@ static gavl_source_status_t decode_rtjpeg_hip(bgav_stream_t *s, gavl_video_frame
     const uint8_t *planes[3];
     int strides[3], i;
     (void)f;
+    /* the application was told frame_width x frame_height (init): a packet whose own header says otherwise would
+     * hand it planes of another size (and a 65520 x 65520 header would ask for gigabytes) — refused, like any
+     * other damaged packet */
+    if (p->buf.len >= 12 &&
+        ((p->buf.buf[6] | (p->buf.buf[7] << 8)) != s->data.video.format->frame_width ||
+         (p->buf.buf[8] | (p->buf.buf[9] << 8)) != s->data.video.format->frame_height)) {
+      gavl_log(GAVL_LOG_ERROR, LOG_DOMAIN, "Packet header %dx%d does not match the stream's %dx%d",
+               p->buf.buf[6] | (p->buf.buf[7] << 8), p->buf.buf[8] | (p->buf.buf[9] << 8),
+               s->data.video.format->frame_width, s->data.video.format->frame_height);
+      bgav_stream_done_packet_read(s, p);
+      return GAVL_SOURCE_EOF;
+    }
     rc = mi_rtj_decode_nocopy(priv->ctx, p->buf.buf, (size_t)p->buf.len, planes, strides);
     if (rc != MI_RTJ_OK) {
       gavl_log(GAVL_LOG_ERROR, LOG_DOMAIN, "Decoding failed: %s", mi_rtj_last_error(priv->ctx));
@@ -117,9 +268,14 @@ static gavl_source_status_t decode_rtjpeg_hip(bgav_stream_t *s, gavl_video_frame
 #endif
 }
 
+#endif /* !MI_RTJ_PIPELINE */
+
 static void close_rtjpeg_hip(bgav_stream_t *s) {
   rtjpeg_hip_priv_t *priv = s->decoder_priv;
   if (!priv) return;
+#ifdef MI_RTJ_PIPELINE
+  mi_rtj_pipe_destroy(priv->pipe);
+#endif
 #ifdef MI_RTJ_NOCOPY
   gavl_video_frame_null(priv->vframe); /* the planes belong to the instance, not to gavl */
   gavl_video_frame_destroy(priv->vframe);
@@ -135,9 +291,15 @@ static bgav_video_decoder_t rtjpeg_hip_decoder = {
     .fourccs = (uint32_t[]){BGAV_MK_FOURCC('R', 'T', 'J', '0'), 0x00},
     .probe = probe_rtjpeg_hip,
     .init = init_rtjpeg_hip,
+#ifdef MI_RTJ_PIPELINE
+    .decode = decode_rtjpeg_pipe,
+    .resync = resync_rtjpeg_pipe,
+    .skipto = skipto_rtjpeg_pipe,
+#else
     .decode = decode_rtjpeg_hip,
-    .close = close_rtjpeg_hip,
     /* synchronous, one packet in / one frame out: no .resync state to flush, no .skipto */
+#endif
+    .close = close_rtjpeg_hip,
 };
 
 #ifdef MI_RTJ_KEEP_CPU_DECODER

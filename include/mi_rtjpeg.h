@@ -65,6 +65,42 @@ int mi_rtj_decode(mi_rtj_ctx *ctx, const uint8_t *pkt, size_t len, uint8_t *cons
  * strides[] describe it (stride = coded width) and stay valid until the next decode call. */
 int mi_rtj_decode_nocopy(mi_rtj_ctx *ctx, const uint8_t *pkt, size_t len, const uint8_t *planes[3],
                          int strides[3]);
+
+/* ---- pipelined session: a frame-owning decoder with packets in flight ----
+ * What a plugin instance that reads ahead uses instead of mi_rtj_decode (the one-packet calls above finish a picture
+ * before they return: copy in, kernels and copy out of successive packets never overlap).  Replaces, for such an
+ * instance, RTjpeg_decompress + gavl_video_frame_copy (lib/video_rtjpeg.c:81-82) with: packets go in in stream order
+ * (their bytes are copied at once into pinned staging: a bgav packet is only valid until the next
+ * bgav_stream_get_packet_read, lib/stream.c:538-601), pictures come out in the same order as pointers into pinned
+ * host memory the session owns (the nocopy source of lib/video.c:420-441; lib/video_v4l2_m2m.c:43-131 is the
+ * in-tree precedent of a decoder with buffers in flight).  Copy in, kernels and copy out of up to `depth` packets
+ * run side by side on three streams; unchanged (0xFF) blocks keep the previous picture of the stream as in the
+ * reference (each packet's device picture starts as a copy of its predecessor's).
+ *   depth            packets in flight plus the one picture on loan, 2..64
+ *   coded_w, coded_h the stream's coded size (multiples of 16; 0 0 = take it from the packets): a packet whose header
+ *                    says otherwise is refused before anything is allocated for it — the reference's frame has the
+ *                    container's size whatever a packet claims (lib/video_rtjpeg.c:50-54)
+ * One session per stream; not thread safe; the instance's header-driven state (mi_rtj_get_state) is shared with
+ * the one-packet calls, which must not be mixed into a running session. */
+typedef struct mi_rtj_pipe mi_rtj_pipe;
+mi_rtj_pipe *mi_rtj_pipe_create(mi_rtj_ctx *ctx, int depth, int coded_w, int coded_h);
+void mi_rtj_pipe_destroy(mi_rtj_pipe *pipe);
+/* packets that can still be submitted before a picture has to be taken / packets in flight */
+int mi_rtj_pipe_room(const mi_rtj_pipe *pipe);
+int mi_rtj_pipe_pending(const mi_rtj_pipe *pipe);
+/* Queue one packet (whole packet, header included).  `tag` comes back with its picture (the wrapper keeps pts,
+ * duration and timecode under it: bgav_set_video_frame_from_packet, lib/video.c:861-871). */
+int mi_rtj_pipe_submit(mi_rtj_pipe *pipe, const uint8_t *pkt, size_t len, uint64_t tag);
+/* The oldest picture in flight: waits for it, then hands out the coded picture (planes[0..2], strides = width,
+ * width/2) — valid until the next mi_rtj_pipe_next / _flush / _destroy.  planes == NULL: the picture is dropped
+ * (bgav's frame skipping, lib/video_rtjpeg.c:75-79; .skipto). */
+int mi_rtj_pipe_next(mi_rtj_pipe *pipe, const uint8_t *planes[3], int strides[3], int *w, int *h, uint64_t *tag);
+/* tag of the oldest picture in flight without waiting for it (for .skipto) */
+int mi_rtj_pipe_peek_tag(const mi_rtj_pipe *pipe, uint64_t *tag);
+/* .resync (include/avdec_private.h:110, lib/video.c:561-562): forget everything in flight.  The stream's previous
+ * picture stays, as priv->frame does in the reference. */
+int mi_rtj_pipe_flush(mi_rtj_pipe *pipe);
+
 /* Geometry and effective quality the last mi_rtj_decode / plan used (RTjpeg_t width/height/Q). */
 void mi_rtj_get_state(const mi_rtj_ctx *ctx, int *width, int *height, int *quality);
 

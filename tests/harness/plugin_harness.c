@@ -4,7 +4,16 @@
  * the small slice of bgav/gavl it needs implemented here (registry as lib/codecs.c:201-279, packet
  * queue behind bgav_stream_get_packet_read, frame metadata copy as lib/video.c:861-871).
  *
- *   plugin_harness <packets.bin> <image_w> <image_h> <out.bin> [skip_every]
+ *   plugin_harness <packets.bin> <image_w> <image_h> <out.bin> [skip_every] [key=value ...]
+ *
+ *   seek=N:M      after N pictures, seek: the packet source continues at packet M and the decoder's .resync is
+ *                 called, as bgav_video_resync does after a seek (lib/video.c:525-565)
+ *   skipto=N:T    after N pictures, bgav_video_skipto(T) the way it runs for streams with keyframes: the decoder's
+ *                 .skipto if it has one, else decode-and-drop (lib/video.c:633-660)
+ *   skippkts=N:T  after N pictures, bgav_video_skipto(T) the way it runs for intra-only streams: packets are
+ *                 skipped at the source, s->out_time is set to the first one kept (lib/video.c:596-612)
+ *   repeat=R      play the packet list R times (time stamps keep counting); bench=1: write no pictures, print
+ *                 {"frames":..,"seconds":..,"fps":..} on stdout (the end-to-end figure of bench.py)
  *
  * packets.bin: repeated { u32 le length, bytes }.  out.bin: for every decoded frame the cropped
  * planes Y (w*h), U, V ((w+1)/2*(h+1)/2 each), tightly packed, followed by 8 bytes pts (le).
@@ -15,6 +24,7 @@
 #include "mi_qtrtj.h"
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <avdec_private.h>
 #include <codecs.h>
@@ -35,11 +45,17 @@ static bgav_video_decoder_t *find_video_decoder(uint32_t fourcc, const gavl_dict
 }
 
 /* ---- packet queue ---- */
-typedef struct { gavl_packet_t *pkts; int n, next; } queue_t;
+typedef struct { gavl_packet_t *pkts; int n, next, repeat, lap; gavl_packet_t cur; } queue_t;
 gavl_source_status_t bgav_stream_get_packet_read(bgav_stream_t *s, bgav_packet_t **p) {
   queue_t *q = s->harness;
-  if (q->next >= q->n) return GAVL_SOURCE_EOF;
-  *p = &q->pkts[q->next++];
+  if (q->next >= q->n) {
+    if (q->lap + 1 >= q->repeat) return GAVL_SOURCE_EOF;
+    q->lap++;
+    q->next = 0;
+  }
+  q->cur = q->pkts[q->next++];
+  q->cur.pts += (int64_t)q->lap * q->n * 40; /* laps keep the time stamps growing */
+  *p = &q->cur;
   return GAVL_SOURCE_OK;
 }
 void bgav_stream_done_packet_read(bgav_stream_t *s, bgav_packet_t *p) { (void)s; (void)p; }
@@ -96,8 +112,18 @@ static int load_mov(const char *path, queue_t *q, uint32_t *fourcc, int *w, int 
 int main(int argc, char **argv) {
   if (argc < 5) return fprintf(stderr, "usage: %s packets.bin|movie.mov w h out.bin [skip_every]  (w h 0 0: from the movie)\n", argv[0]), 1;
   int iw = atoi(argv[2]), ih = atoi(argv[3]);
-  const int skip_every = argc > 5 ? atoi(argv[5]) : 0;
+  int skip_every = 0, seek_at = -1, seek_to = 0, skipto_at = -1, skippkts_at = -1, bench = 0;
+  long long skipto_t = 0, skippkts_t = 0;
   queue_t q = {0};
+  q.repeat = 1;
+  for (int i = 5; i < argc; i++) {
+    if (sscanf(argv[i], "seek=%d:%d", &seek_at, &seek_to) == 2) continue;
+    if (sscanf(argv[i], "skipto=%d:%lld", &skipto_at, &skipto_t) == 2) continue;
+    if (sscanf(argv[i], "skippkts=%d:%lld", &skippkts_at, &skippkts_t) == 2) continue;
+    if (sscanf(argv[i], "repeat=%d", &q.repeat) == 1) continue;
+    if (sscanf(argv[i], "bench=%d", &bench) == 1) continue;
+    skip_every = atoi(argv[i]);
+  }
   uint32_t fourcc = BGAV_MK_FOURCC('R', 'T', 'J', '0');
   const size_t plen = strlen(argv[1]);
   if (plen > 4 && strcmp(argv[1] + plen - 4, ".mov") == 0) {
@@ -152,11 +178,37 @@ int main(int argc, char **argv) {
   f.planes[1] = malloc((size_t)f.strides[1] * ch);
   f.planes[2] = malloc((size_t)f.strides[2] * ch);
 
-  FILE *fo = fopen(argv[4], "wb");
-  if (!fo) return perror(argv[4]), 1;
+  FILE *fo = bench ? NULL : fopen(argv[4], "wb");
+  if (!fo && !bench) return perror(argv[4]), 1;
   int nframes = 0, k = 0;
+  struct timespec t0, t1;
+  s.out_time = q.n ? q.pkts[0].pts : 0; /* STREAM_GET_SYNC at start (lib/video.c:527-528) */
+  clock_gettime(CLOCK_MONOTONIC, &t0);
   for (;;) {
     const gavl_video_frame_t *res;
+    if (nframes == seek_at) { /* a seek: the demultiplexer repositions, then bgav_video_resync (lib/video.c:525-565) */
+      seek_at = -1;
+      q.next = seek_to;
+      s.out_time = q.pkts[seek_to].pts;
+      if (dec->resync) dec->resync(&s);
+    }
+    if (nframes == skippkts_at) { /* bgav_video_skipto, intra-only branch (lib/video.c:596-612) */
+      skippkts_at = -1;
+      while (q.next < q.n && q.pkts[q.next].pts + q.pkts[q.next].duration <= skippkts_t) q.next++;
+      if (q.next < q.n) s.out_time = q.pkts[q.next].pts;
+    }
+    if (nframes == skipto_at) { /* bgav_video_skipto, keyframe branch (lib/video.c:633-660) */
+      skipto_at = -1;
+      if (dec->skipto) {
+        if (!dec->skipto(&s, skipto_t)) break;
+      } else {
+        for (;;) { /* decode and drop until the picture that ends after the target */
+          gavl_packet_t *nx = q.next < q.n ? &q.pkts[q.next] : NULL;
+          if (!nx || nx->pts + nx->duration > skipto_t) break;
+          if (dec->decode(&s, s.vframe ? NULL : &f) != GAVL_SOURCE_OK) break;
+        }
+      }
+    }
     if (s.vframe) { /* read_video_nocopy (lib/video.c:253-277): decode(s, NULL), picture in s->vframe */
       if (dec->decode(&s, NULL) != GAVL_SOURCE_OK) break;
       res = s.vframe;
@@ -166,13 +218,27 @@ int main(int argc, char **argv) {
       if (skip) continue;
       res = &f;
     }
-    for (int y = 0; y < ih; y++) fwrite(res->planes[0] + (size_t)y * res->strides[0], 1, iw, fo);
-    for (int pl = 1; pl < 3; pl++)
-      for (int y = 0; y < ch; y++) fwrite(res->planes[pl] + (size_t)y * res->strides[pl], 1, cw, fo);
-    fwrite(&res->timestamp, 8, 1, fo);
+    s.out_time = res->timestamp + res->duration; /* lib/video.c:274,295 */
+    if (fo) {
+      for (int y = 0; y < ih; y++) fwrite(res->planes[0] + (size_t)y * res->strides[0], 1, iw, fo);
+      for (int pl = 1; pl < 3; pl++)
+        for (int y = 0; y < ch; y++) fwrite(res->planes[pl] + (size_t)y * res->strides[pl], 1, cw, fo);
+      fwrite(&res->timestamp, 8, 1, fo);
+    } else { /* bench: touch the picture like a consumer would (one byte per 4 KiB page of every plane) */
+      volatile unsigned acc = 0;
+      for (size_t o = 0; o < (size_t)res->strides[0] * ih; o += 4096) acc += res->planes[0][o];
+      for (int pl = 1; pl < 3; pl++)
+        for (size_t o = 0; o < (size_t)res->strides[pl] * ch; o += 4096) acc += res->planes[pl][o];
+      (void)acc;
+    }
     nframes++;
   }
-  fclose(fo);
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  if (fo) fclose(fo);
+  if (bench) {
+    const double sec = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    printf("{\"frames\": %d, \"seconds\": %.6f, \"fps\": %.1f, \"decoder\": \"%s\"}\n", nframes, sec, nframes / sec, dec->name);
+  }
   dec->close(&s); /* bgav_video_stop (lib/video.c:510-514) */
   fprintf(stderr, "%d frames\n", nframes);
   return 0;

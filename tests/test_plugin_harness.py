@@ -89,3 +89,113 @@ def test_wrapper_decodes_like_the_reference_wrapper(tmp_path, w, h, iw, ih, key_
         rec = raw[i * (fsz + 8):(i + 1) * (fsz + 8)]
         assert np.array_equal(rec[:fsz], planes), i
         assert struct.unpack("<q", rec[fsz:].tobytes())[0] == pts
+
+
+# --------------------------------------------------------------------------- the read-ahead (pipelined) flavour
+PIPE = HARNESS_COPY + "_pipe"
+
+
+def run_pipe(tmp_path, pkts, iw, ih, *opts, depth=None):
+    pk, out = tmp_path / "p.bin", tmp_path / "o.bin"
+    write_packets(pk, pkts)
+    env = dict(os.environ)
+    if depth:
+        env["MI_RTJ_DEPTH"] = str(depth)
+    r = subprocess.run([PIPE, str(pk), str(iw), str(ih), str(out)] + list(opts), capture_output=True, text=True, env=env)
+    fsz = iw * ih + 2 * ((iw + 1) // 2) * ((ih + 1) // 2)
+    raw = np.fromfile(out, dtype=np.uint8) if os.path.exists(out) else np.zeros(0, np.uint8)
+    recs = [(raw[i * (fsz + 8): i * (fsz + 8) + fsz], struct.unpack("<q", raw[i * (fsz + 8) + fsz:(i + 1) * (fsz + 8)].tobytes())[0])
+            for i in range(raw.size // (fsz + 8))]
+    return r, recs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,iw,ih,key_rate,depth", [(320, 240, 320, 240, 0, None), (320, 240, 314, 234, 4, 2),
+                                                      (1920, 1088, 1920, 1080, 5, 3), (160, 128, 160, 121, 3, 16)])
+def test_pipelined_decoder_hands_out_the_same_pictures_in_order(tmp_path, w, h, iw, ih, key_rate, depth):
+    """packets in flight, pictures out in stream order with their own time stamps; streams with unchanged blocks keep
+    their history although several packets are on the device at once"""
+    build_harness()
+    enc = R.OracleEncoder(w, h, 220, key_rate, 2, 2)
+    n = 5 if w >= 1920 else 23
+    pkts = [enc.encode(R.synth_frame(w, h, i // 2, seed=21, amp=4)) for i in range(n)]
+    r, recs = run_pipe(tmp_path, pkts, iw, ih, depth=depth)
+    assert r.returncode == 0, r.stderr
+    want = expected_stream(pkts, w, h, iw, ih, 0)
+    assert len(recs) == len(want)
+    for i, ((got, pts), (planes, wpts)) in enumerate(zip(recs, want)):
+        assert np.array_equal(got, planes), i
+        assert pts == wpts
+
+
+@pytest.mark.gpu
+def test_pipelined_decoder_resync_mid_stream_drops_what_was_read_ahead(tmp_path):
+    """a seek after 5 pictures to packet 14 (intra-only stream): pictures 0-4, then 14 onwards — nothing of the
+    packets that were in flight when .resync came"""
+    build_harness()
+    w, h = 320, 240
+    enc = R.OracleEncoder(w, h, 200)
+    pkts = [enc.encode(R.synth_frame(w, h, i, seed=5, amp=10)) for i in range(20)]
+    r, recs = run_pipe(tmp_path, pkts, w, h, "seek=5:14", depth=6)
+    assert r.returncode == 0, r.stderr
+    want = expected_stream(pkts, w, h, w, h, 0)
+    order = list(range(5)) + list(range(14, 20))
+    assert [pts for _, pts in recs] == [want[i][1] for i in order]
+    for (got, _), i in zip(recs, order):
+        assert np.array_equal(got, want[i][0]), i
+
+
+@pytest.mark.gpu
+def test_pipelined_decoder_drops_stale_pictures_after_a_packet_skip(tmp_path):
+    """bgav_video_skipto on an intra-only stream skips packets at the source and sets s->out_time (lib/video.c:596-612);
+    pictures of packets read ahead before that must not come out"""
+    build_harness()
+    w, h = 320, 240
+    enc = R.OracleEncoder(w, h, 200)
+    pkts = [enc.encode(R.synth_frame(w, h, i, seed=6, amp=10)) for i in range(20)]
+    # after 3 pictures skip to t = 1000 + 40 * 12 + 1: packets whose pts + 40 <= t go, i.e. 0..11
+    r, recs = run_pipe(tmp_path, pkts, w, h, f"skippkts=3:{1000 + 40 * 12 + 1}", depth=6)
+    assert r.returncode == 0, r.stderr
+    want = expected_stream(pkts, w, h, w, h, 0)
+    order = list(range(3)) + list(range(12, 20))
+    assert [pts for _, pts in recs] == [want[i][1] for i in order]
+    for (got, _), i in zip(recs, order):
+        assert np.array_equal(got, want[i][0]), i
+
+
+@pytest.mark.gpu
+def test_pipelined_decoder_skipto_decodes_every_packet_and_drops_pictures(tmp_path):
+    """.skipto on a stream with unchanged blocks: every packet still goes through the decoder (the history must be
+    right), pictures before the target are dropped"""
+    build_harness()
+    w, h = 320, 240
+    enc = R.OracleEncoder(w, h, 210, 6, 3, 3)
+    pkts = [enc.encode(R.synth_frame(w, h, i // 3, seed=7, amp=3)) for i in range(18)]
+    assert any((p[12:] == 255).any() for p in pkts)
+    r, recs = run_pipe(tmp_path, pkts, w, h, f"skipto=2:{1000 + 40 * 9 + 5}", depth=4)
+    assert r.returncode == 0, r.stderr
+    want = expected_stream(pkts, w, h, w, h, 0)
+    order = [0, 1] + list(range(9, 18))
+    assert [pts for _, pts in recs] == [want[i][1] for i in order]
+    for (got, _), i in zip(recs, order):
+        assert np.array_equal(got, want[i][0]), i
+
+
+@pytest.mark.gpu
+def test_pipelined_decoder_refuses_a_packet_of_another_size(tmp_path):
+    """a packet whose header announces another picture size than the stream's is a damaged packet: the pictures
+    before it come out, then the stream ends (EOF + a log line), nothing is allocated for the claimed size"""
+    build_harness()
+    w, h = 320, 240
+    enc = R.OracleEncoder(w, h, 200)
+    pkts = [enc.encode(R.synth_frame(w, h, i, seed=8, amp=10)) for i in range(8)]
+    bad = pkts[5].copy()
+    bad[6], bad[7], bad[8], bad[9] = 0xF0, 0xFF, 0xF0, 0xFF  # 65520 x 65520
+    pkts[5] = bad
+    r, recs = run_pipe(tmp_path, pkts, w, h, depth=3)
+    assert r.returncode == 0
+    assert "does not match the stream's coded size" in r.stderr
+    want = expected_stream(pkts[:5], w, h, w, h, 0)
+    assert len(recs) == 5
+    for (got, _), (planes, _) in zip(recs, want):
+        assert np.array_equal(got, planes)

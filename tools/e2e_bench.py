@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""End-to-end (host packets in, host pictures out) frames per second through the plugin seam: the three flavours of
+csrc/video_rtjpeg_mi355x.c driven by tests/harness/plugin_harness.c in bench mode.  Prints one JSON object.
+
+    python tools/e2e_bench.py [--width 1920 --height 1088 --packets 64 --repeat 32 --depth 6]
+"""
+import argparse, importlib, json, os, struct, subprocess, sys, tempfile
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def run(width=1920, height=1088, packets=64, repeat=32, depth=4, quality=255, amp=8, flavours=("", "_nocopy", "_pipe")):
+    P = importlib.import_module("gmerlin-avdecoder_amd")
+    dev = P.MiRtj(0)
+    d_fr = dev.synth(width, height, 0, packets, seed=12345, amp=amp)
+    d_st, po, pl = dev.encode(width, height, quality, packets, d_fr)
+    dev.sync()
+    tmp = tempfile.mkdtemp(prefix="mi_rtj_e2e_")
+    path = os.path.join(tmp, "p.bin")
+    with open(path, "wb") as fh:
+        for i in range(packets):
+            pkt = dev.d2h(d_st, int(pl[i]), offset=int(po[i]))
+            fh.write(struct.pack("<I", pkt.size))
+            fh.write(pkt.tobytes())
+    dev.free(d_fr); dev.free(d_st); dev.close()
+    subprocess.run(["make", "-C", os.path.join(ROOT, "gmerlin-avdecoder_amd", "csrc")], check=True, capture_output=True)
+    out = {"workload": f"{packets} RTjpeg {width}x{height} Q={quality} packets x {repeat} laps, display {width}x{height - 8 if height == 1088 else height}",
+           "pcie_cap_fps": round(55e9 / (width * height * 1.5), 0)}
+    for fl in flavours:
+        exe = os.path.join(ROOT, "gmerlin-avdecoder_amd", "lib", "plugin_harness" + fl)
+        env = dict(os.environ, MI_RTJ_DEPTH=str(depth))
+        ih = height - 8 if height == 1088 else height
+        r = subprocess.run([exe, path, str(width), str(ih), "/dev/null", f"repeat={repeat}", "bench=1"], capture_output=True, text=True, env=env, timeout=600)
+        name = {"": "copy (synchronous, caller's planes)", "_nocopy": "frame-owning (synchronous)", "_pipe": f"frame-owning, {depth} packets in flight"}[fl]
+        try:
+            out[name] = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception:
+            out[name] = {"error": (r.stderr or r.stdout)[-300:]}
+    os.remove(path); os.rmdir(tmp)
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=int, default=1920); ap.add_argument("--height", type=int, default=1088)
+    ap.add_argument("--packets", type=int, default=64); ap.add_argument("--repeat", type=int, default=32)
+    ap.add_argument("--depth", type=int, default=4)
+    a = ap.parse_args()
+    print(json.dumps(run(a.width, a.height, a.packets, a.repeat, a.depth)))
