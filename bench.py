@@ -13,9 +13,10 @@ Workloads (`config.workload` in the output names the one that ran):
               dequant/IDCT/plane scatter) over `--frames` distinct synthetic RTjpeg frames per GPU that are already
               resident in HBM (coded 1920x1088 = display 1080p, YUV420, Q=255, intra only; SURVEY.md §8d cfg 2).
               Frames, streams and outputs never leave the device inside the timed region.  Weak scaling.
-  streams4k   (configs[3]) one 3840x2160 stream WITH unchanged (0xFF) blocks per GPU, decoded in order, one packet
-              per call, through the entry point the plugin uses (host packet in, host planes out: PCIe included).
-              A step is one pass over the stream's `--frames` packets.
+  streams4k   (configs[3]) one 3840x2160 stream WITH unchanged (0xFF) blocks per GPU, decoded in order through a
+              pipelined session (mi_rtj_pipe_*, what the frame-owning plugin instance uses): host packets in, host
+              pictures out, PCIe both ways inside the timed region.  A step is one pass over the stream's `--frames`
+              packets.
   mixed       (configs[4]) 64 intra-only streams of mixed geometry and quality, frames dealt cyclically to the
               ranks, one plan per rank, every frame of every rank compared with the CPU oracle.
 
@@ -69,6 +70,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="budget of each CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU legs (and with them the parity check)")
     ap.add_argument("--no-stress", action="store_true", help="skip the short second measurement on noisy content")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (plugin harness) measurement")
     ap.add_argument("--verify-frames", type=int, default=256, help="frames of the batch compared with the CPU decoder")
     ap.add_argument("--selftest-ranks", action="store_true",
                     help="no GPU work: every rank reports a dummy shard through the same reduction (launcher test)")
@@ -364,6 +366,18 @@ def main():
             out["parity_mismatches"] = mismatches
             out["speedup_vs_cpu_1core"] = round(fps / one["value"], 1)
             out["speedup_vs_cpu_all_cores"] = round(fps / allc["value"], 1) if allc["value"] else None
+        # end to end through the plugin seam (host packets in, host pictures out; SURVEY 8d "End-to-end vs kernel (ii)"):
+        # the C wrapper driven by tests/harness/plugin_harness.c in bench mode — never part of `value`
+        if world == 1 and not a.no_e2e:
+            try:
+                e2e = importlib.import_module("tools.e2e_bench")
+                r2 = e2e.run(w, h, packets=min(n, 64), repeat=16)
+                out["end_to_end"] = {"fps": max((v.get("fps", 0) for v in r2.values() if isinstance(v, dict)), default=0),
+                                     "pcie_cap_fps": r2["pcie_cap_fps"], "by_flavour": {k: v for k, v in r2.items() if isinstance(v, dict)},
+                                     "note": "one stream, one host thread, through csrc/video_rtjpeg_mi355x.c; fps = the best "
+                                             "flavour (frame-owning with packets in flight); cap = 55 GB/s PCIe / picture bytes"}
+            except Exception as exc:  # the harness is a convenience here, not the measurement
+                out["end_to_end"] = {"error": str(exc)[:200]}
         # what a plain streaming copy kernel sustains on this device (read + write), measured now: the second
         # yardstick of SURVEY.md section 8d next to the nominal peak (it overwrites half of the output: after the check)
         half = (fsz * n // 2) & ~15

@@ -1,0 +1,172 @@
+"""bench.py's workloads for BASELINE.json configs[3] and configs[4] (SURVEY.md section 8d cfg 4 / cfg 5).
+
+streams4k  one 3840x2160 stream WITH unchanged (0xFF) blocks per rank (stream i -> rank i, shard.streams_for_rank),
+           decoded in order through a pipelined session (mi_rtj_pipe_*: the entry points the frame-owning plugin
+           instance uses): host packets in, host pictures out, PCIe both ways inside the timed region.
+mixed      64 intra-only streams of mixed geometry (320x240, 1920x1088, 3840x2160) and quality (64, 128, 255); the
+           frames of all streams are dealt cyclically to the ranks (shard.frames_for_rank(..., "cyclic")), each rank
+           decodes its share as one plan, resident in HBM, and EVERY frame of every rank is compared with the CPU
+           decoder.
+
+Each returns (the JSON object rank 0 prints, mismatches seen by this rank)."""
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _checker():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import rtjlib as R  # the CPU checker (oracle / reference build): parity only, never measured here
+    return R
+
+
+def _digest(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:32]
+
+
+def _cpu_digests(args):
+    """worker: decode packets in order with one CPU decoder, return the pictures' digests"""
+    pkts, = args
+    R = _checker()
+    dec = R.OracleDecoder()
+    out = []
+    pic = np.zeros(0, np.uint8)
+    for p in pkts:
+        w, h = int(p[6]) | (int(p[7]) << 8), int(p[8]) | (int(p[9]) << 8)
+        if pic.size != w * h * 3 // 2:
+            pic = np.zeros(w * h * 3 // 2, np.uint8)  # the stream's picture: unchanged (0xFF) blocks keep what it holds
+        dec.decode(p, pic)
+        out.append(_digest(pic))
+    return out
+
+
+def run_streams4k(a, dev, shard, dist, red_dev, rank, world, barrier, sync_all, force_dist):
+    w, h, Q = 3840, 2160, a.quality
+    nf = a.frames or 48
+    (stream_id,) = shard.streams_for_rank(world, rank, world)  # as many streams as ranks: stream i on rank i
+    d_fr = dev.synth(w, h, stream_id * 1000, nf, seed=a.seed + stream_id, amp=a.amp)
+    d_st, po, pl = dev.encode(w, h, Q, nf, d_fr, key_rate=12, lmask=1, cmask=1)
+    dev.sync()
+    dev.free(d_fr)
+    pkts = [dev.d2h(d_st, int(pl[i]), offset=int(po[i])) for i in range(nf)]
+    dev.free(d_st)
+    pipe = dev.pipe(depth=4, coded_w=w, coded_h=h)
+
+    def lap(check=None):
+        got, nxt = 0, 0
+        while got < nf:
+            while nxt < nf and pipe.room() > 0:
+                pipe.submit(pkts[nxt], nxt)
+                nxt += 1
+            y, u, v, tag = pipe.next()
+            if check is not None and tag < len(check):
+                check[tag] = _digest(np.concatenate([y, u, v]))
+            got += 1
+
+    ncheck = min(nf, 6)
+    mine = [None] * ncheck
+    lap(mine)  # first lap: also the warm-up; its first pictures are compared (the stream starts from a blank picture)
+    for _ in range(max(a.warmup - 1, 0)):
+        lap()
+    barrier()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        lap()
+    sync_all()
+    barrier()
+    dt = time.perf_counter() - t0
+    pipe.close()
+    want = _cpu_digests((pkts[:ncheck],))
+    mism = sum(int(x != y) for x, y in zip(mine, want))
+    rep = shard.reduce_report(shard.Report(nf, nf * w * h, mism, dt), dist, device=red_dev, force=force_dist)
+    fps = rep.frames * a.steps / rep.elapsed
+    out = {"metric": "RTjpeg 3840x2160 decode frames/sec, in-order streams, host to host", "value": round(fps, 1),
+           "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": round(rep.elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "i32", "data": "synthetic",
+           "config": {"workload": f"{world} RTjpeg 3840x2160 YUV420 Q={Q} streams with unchanged (0xFF) blocks "
+                                  f"(key_rate 12), one per GPU, {nf} packets each, decoded in order through a pipelined "
+                                  f"session, host packets in / host pictures out (BASELINE configs[3])",
+                       "frames_per_stream": nf, "avg_packet_bytes": int(sum(p.size for p in pkts) // nf),
+                       "sharding": "streams, one per GPU, no data-path collective"},
+           "mpixels_per_s": round(fps * w * h / 1e6, 1),
+           "pcie_cap_frames_per_s_per_gpu": round(55e9 / (w * h * 1.5), 0),
+           "parity_checked": rep.frames and ncheck * world, "parity_mismatches": rep.mismatches}
+    return out, mism
+
+
+GEOMS = [(320, 240), (1920, 1088), (3840, 2160)]
+QUALS = [64, 128, 255]
+
+
+def run_mixed(a, dev, shard, dist, red_dev, rank, world, barrier, sync_all, force_dist):
+    nstreams, per = 64, a.frames or 4
+    total = nstreams * per
+    mine = shard.frames_for_rank(total, rank, world, "cyclic")  # frame k = stream k // per, picture k % per
+    # make this rank's packets on the device, one (geometry, quality) group at a time, then bring them together
+    pkts = {}
+    groups = {}
+    for k in mine:
+        s = k // per
+        groups.setdefault((GEOMS[s % 3], QUALS[(s // 3) % 3]), []).append(k)
+    for ((w, h), Q), ks in groups.items():
+        for k in ks:  # content depends on (stream, picture) only, whatever the rank
+            d_fr = dev.synth(w, h, k, 1, seed=a.seed + k // per, amp=a.amp)
+            d_st, po, pl = dev.encode(w, h, Q, 1, d_fr)
+            dev.sync()
+            pkts[k] = dev.d2h(d_st, int(pl[0]), offset=int(po[0]))
+            dev.free(d_fr)
+            dev.free(d_st)
+    order = sorted(pkts)
+    plist = [pkts[k] for k in order]
+    d_stream, po, pl, hdrs = dev.upload_packets(plist, align=64)
+    sizes = [(int(p[6]) | (int(p[7]) << 8)) * (int(p[8]) | (int(p[9]) << 8)) * 3 // 2 for p in plist]
+    oo = np.concatenate([[0], np.cumsum([(s + 255) // 256 * 256 for s in sizes])]).astype(np.uint64)
+    d_out = dev.alloc(int(oo[-1]))
+    plan = dev.plan(hdrs, po, pl, oo[:-1].copy())
+    for _ in range(a.warmup):
+        plan.decode(d_stream, d_out)
+    barrier()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        plan.decode(d_stream, d_out)
+    sync_all()
+    barrier()
+    dt = time.perf_counter() - t0
+    # every picture of this rank against the CPU decoder (one decoder per picture: the plan applies the header state
+    # machine in plan order, and so does a fresh CPU decoder given the same packet alone, since every packet carries
+    # a non-zero quality)
+    got = [_digest(dev.d2h(d_out, sizes[i], offset=int(oo[i]))) for i in range(len(plist))]
+    import multiprocessing as mp
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
+    with mp.get_context("spawn").Pool(cores) as pool:
+        res = pool.map(_cpu_digests, [([p],) for p in plist])
+    mism = sum(int(g != r[0]) for g, r in zip(got, res))
+    pixels = sum(s * 2 // 3 for s in sizes)
+    plan.close()
+    dev.free(d_stream)
+    dev.free(d_out)
+    rep = shard.reduce_report(shard.Report(len(plist), pixels, mism, dt), dist, device=red_dev, force=force_dist)
+    fps = rep.frames * a.steps / rep.elapsed
+    out = {"metric": "RTjpeg decode frames/sec, mixed batch", "value": round(fps, 1), "unit": "frames/s",
+           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(rep.elapsed / a.steps * 1e3, 4),
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "i32", "data": "synthetic",
+           "config": {"workload": f"{nstreams} intra-only RTjpeg streams x {per} pictures, geometries 320x240 / 1920x1088 / "
+                                  f"3840x2160, Q 64 / 128 / 255, frame-level cyclic scatter over {world} GPU(s), one plan per "
+                                  f"GPU resident in HBM (BASELINE configs[4])",
+                       "frames_total": rep.frames, "sharding": "frames, cyclic, no data-path collective"},
+           "mpixels_per_s": round(rep.pixels * a.steps / rep.elapsed / 1e6, 1),
+           "parity_checked": rep.frames, "parity_mismatches": rep.mismatches}
+    return out, mism
+
+
+def run(a, dev, P, shard, dist, red_dev, rank, world, barrier, sync_all, force_dist):
+    fn = run_streams4k if a.config == "streams4k" else run_mixed
+    return fn(a, dev, shard, dist, red_dev, rank, world, barrier, sync_all, force_dist)

@@ -178,6 +178,51 @@ class Plan:
         return a
 
 
+class Pipe:
+    """View of mi_rtj_pipe (include/mi_rtjpeg.h, "pipelined session") for tests and bench.py."""
+
+    def __init__(self, owner, depth, coded_w, coded_h):
+        self.owner = owner
+        self.h = owner.L.mi_rtj_pipe_create(owner.h, depth, coded_w, coded_h)
+        if not self.h:
+            raise MiRtjError("mi_rtj_pipe_create failed: " + owner.L.mi_rtj_last_error(owner.h).decode())
+
+    def close(self):
+        if self.h:
+            self.owner.L.mi_rtj_pipe_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def room(self):
+        return self.owner.L.mi_rtj_pipe_room(self.h)
+
+    def pending(self):
+        return self.owner.L.mi_rtj_pipe_pending(self.h)
+
+    def submit(self, pkt, tag=0):
+        pkt = np.ascontiguousarray(pkt, dtype=np.uint8)
+        self.owner._chk(self.owner.L.mi_rtj_pipe_submit(self.h, pkt.ctypes.data_as(u8p), pkt.size, tag))
+
+    def next(self, drop=False):
+        """(y, u, v, tag): numpy views of the session's pinned picture, valid until the next call; drop: tag only."""
+        tag = C.c_uint64()
+        if drop:
+            self.owner._chk(self.owner.L.mi_rtj_pipe_next(self.h, None, None, None, None, C.byref(tag)))
+            return tag.value
+        planes = (u8p * 3)()
+        st = (C.c_int * 3)()
+        w, h = C.c_int(), C.c_int()
+        self.owner._chk(self.owner.L.mi_rtj_pipe_next(self.h, planes, st, C.byref(w), C.byref(h), C.byref(tag)))
+        mk = lambda p, n: np.ctypeslib.as_array(p, shape=(n,))
+        n = w.value * h.value
+        return mk(planes[0], n), mk(planes[1], n // 4), mk(planes[2], n // 4), tag.value
+
+    def flush(self):
+        self.owner._chk(self.owner.L.mi_rtj_pipe_flush(self.h))
+
+
 class MiRtj:
     """One decoder instance (== one RTjpeg_t of the reference) bound to one device."""
 
@@ -234,6 +279,10 @@ class MiRtj:
         h = int(pkt[8]) | (int(pkt[9]) << 8)
         mk = lambda p, n: np.ctypeslib.as_array(p, shape=(n,))
         return mk(planes[0], w * h), mk(planes[1], w * h // 4), mk(planes[2], w * h // 4)
+
+    def pipe(self, depth=4, coded_w=0, coded_h=0):
+        """A pipelined session (mi_rtj_pipe_*): packets in, pictures out in order, several in flight."""
+        return Pipe(self, depth, coded_w, coded_h)
 
     def state(self):
         w, h, q = C.c_int(), C.c_int(), C.c_int()
