@@ -84,17 +84,20 @@ int mi_dv_video_packet(const mi_dv_profile *p, const uint8_t *frame, uint8_t *ou
   return p->frame_size;
 }
 
+/* 12-bit non-linear PCM to 16 bits (IEC 61834-2, the expansion dv_audio_12to16 implements, lib/dvframe.c:521-543).
+ * Written from the companding law rather than from the reference's arithmetic: magnitudes are coded in eight
+ * segments of 256 codes; segments 0 and 1 are linear, segment k >= 2 covers a range 2^(k-1) times as wide, i.e.
+ * value = (code - 256 (k - 1)) << (k - 1).  Negative samples are the one's complement of the positive law
+ * (code -> ~code, value -> ~value), which is what makes the two halves of the reference's formula one rule. */
+static unsigned expand_magnitude(unsigned m) { /* m: 0 .. 0x7ff */
+  const unsigned k = m >> 8;
+  return k < 2 ? m : (m - 256u * (k - 1u)) << (k - 1u);
+}
+
 uint16_t mi_dv_audio_12to16(uint16_t sample) {
-  uint16_t shift;
-  sample = (uint16_t)(sample < 0x800 ? sample : sample | 0xf000);
-  shift = (uint16_t)((sample & 0xf00) >> 8);
-  if (shift < 0x2 || shift > 0xd) return sample;
-  if (shift < 0x8) {
-    shift--;
-    return (uint16_t)((sample - 256 * shift) << shift);
-  }
-  shift = (uint16_t)(0xe - shift);
-  return (uint16_t)(((sample + (256 * shift + 1)) << shift) - 1);
+  const unsigned s = sample & 0xfffu;
+  if (s & 0x800u) return (uint16_t)~expand_magnitude(~s & 0x7ffu);
+  return (uint16_t)expand_magnitude(s);
 }
 
 static const int audio_hz[3] = {48000, 44100, 32000};
@@ -111,56 +114,68 @@ int mi_dv_audio_format(const mi_dv_profile *p, const uint8_t *frame, int *sample
   return 1;
 }
 
+/* ---- audio de-shuffle (what dv_extract_audio does, lib/dvframe.c:545-628), written from the DIF layout ----
+ * A frame is n_difchan channels of difseg_size DIF sequences of 150 DIF blocks of 80 bytes.  Within a sequence,
+ * block 0 is the header, 1-2 subcode, 3-5 VAUX, and then nine times (1 audio block, 15 video blocks): audio block j
+ * of sequence q of channel c is DIF block (c * difseg_size + q) * 150 + 6 + 16 j.  An audio block is 3 bytes ID,
+ * a 5-byte AAUX pack and 72 bytes of samples:
+ *   16-bit mode  36 big-endian samples; sample n goes to slot shuffle[q][j] + n * stride of the channel's pair
+ *   12-bit mode  24 byte triples (left high 8, right high 8, low nibbles of both); the sequences of a channel's
+ *                first half fill one stereo pair, those of its second half the next one; the left sample of triple
+ *                n goes to slot shuffle[q mod half][j] + n * stride, the right one to the slot the sequence `half`
+ *                further on would use
+ * A slot is a 16-bit little-endian sample in the pair's buffer. */
+enum { DIF_BLOCK = 80, DIF_SEQ_BLOCKS = 150, AUDIO_FIRST = 6, AUDIO_EVERY = 16, AUDIO_PER_SEQ = 9, AUDIO_PAYLOAD = 8 };
+
+static void put_le16(uint8_t *pcm, int slot, unsigned v) {
+  pcm[2 * slot] = (uint8_t)(v & 0xffu);
+  pcm[2 * slot + 1] = (uint8_t)(v >> 8);
+}
+
 int mi_dv_extract_audio(const mi_dv_profile *p, const uint8_t *frame, uint8_t *ppcm[4]) {
   const uint8_t *as = fixed_pack(frame, PACK_AUDIO_SOURCE);
   if (!as) return 0; /* no audio */
-  const int smpls = as[1] & 0x3f;       /* samples in this frame beyond the minimum */
+  const int extra = as[1] & 0x3f;       /* samples in this frame beyond the profile's minimum */
   const int freq = (as[4] >> 3) & 0x07; /* 0: 48 kHz, 1: 44.1 kHz, 2: 32 kHz */
-  const int quant = as[4] & 0x07;       /* 0: 16 bit linear, 1: 12 bit non-linear */
-  if (quant > 1 || freq > 2) return -1;
-  const int size = (p->audio_min_samples[freq] + smpls) * 4; /* 2 channels x 2 bytes */
-  const int half_ch = p->difseg_size / 2;
-  /* 720p frames come in halves: even ones carry channel pairs 0,1, odd ones 2,3 */
-  int ipcm = (p->height == 720 && ((frame[1] >> 2) & 0x3) == 0) ? 2 : 0;
-  uint8_t *pcm = ppcm[ipcm++];
+  const int twelve = (as[4] & 0x07) == 1;
+  if ((as[4] & 0x07) > 1 || freq > 2) return -1;
+  const int slots = (p->audio_min_samples[freq] + extra) * 2; /* 16-bit slots per stereo pair buffer */
+  const int half = p->difseg_size / 2;
+  /* 720p frames come in halves: the first one carries channel pairs 2 and 3 (as the reference has it) */
+  const int first_pair = (p->height == 720 && ((frame[1] >> 2) & 0x3) == 0) ? 2 : 0;
 
-  for (int chan = 0; chan < p->n_difchan; chan++) {
-    for (int i = 0; i < p->difseg_size; i++) {
-      frame += 6 * 80; /* header, subcode and VAUX blocks of the sequence */
-      if (quant == 1 && i == half_ch) { /* second stereo pair (12-bit mode only) */
-        pcm = ppcm[ipcm++];
-        if (!pcm) break;
-      }
-      for (int j = 0; j < 9; j++) { /* nine audio DIF blocks per sequence */
-        for (int d = 8; d < 80; d += 2) {
-          if (quant == 0) {
-            const int of = p->audio_shuffle[i][j] + (d - 8) / 2 * p->audio_stride;
-            if (of * 2 >= size) continue;
-            pcm[of * 2] = frame[d + 1]; /* DV PCM is big endian */
-            pcm[of * 2 + 1] = frame[d];
-            if (pcm[of * 2 + 1] == 0x80 && pcm[of * 2] == 0x00) pcm[of * 2 + 1] = 0; /* error code -> silence */
-          } else {
-            uint16_t lc = (uint16_t)(((uint16_t)frame[d] << 4) | ((uint16_t)frame[d + 2] >> 4));
-            uint16_t rc = (uint16_t)(((uint16_t)frame[d + 1] << 4) | ((uint16_t)frame[d + 2] & 0x0f));
-            lc = lc == 0x800 ? 0 : mi_dv_audio_12to16(lc);
-            rc = rc == 0x800 ? 0 : mi_dv_audio_12to16(rc);
-            int of = p->audio_shuffle[i % half_ch][j] + (d - 8) / 3 * p->audio_stride;
-            if (of * 2 >= size) continue;
-            pcm[of * 2] = (uint8_t)(lc & 0xff);
-            pcm[of * 2 + 1] = (uint8_t)(lc >> 8);
-            of = p->audio_shuffle[i % half_ch + half_ch][j] + (d - 8) / 3 * p->audio_stride;
-            pcm[of * 2] = (uint8_t)(rc & 0xff);
-            pcm[of * 2 + 1] = (uint8_t)(rc >> 8);
-            ++d; /* three bytes carry two 12-bit samples */
+  for (int c = 0; c < p->n_difchan; c++) {
+    for (int q = 0; q < p->difseg_size; q++) {
+      const int pair = first_pair + (twelve ? 2 * c + (q >= half) : c);
+      uint8_t *pcm = pair < 4 ? ppcm[pair] : NULL;
+      if (!pcm) return slots / 2; /* the caller wants no more pairs than it gave buffers for */
+      for (int j = 0; j < AUDIO_PER_SEQ; j++) {
+        const uint8_t *blk =
+            frame + ((size_t)(c * p->difseg_size + q) * DIF_SEQ_BLOCKS + AUDIO_FIRST + AUDIO_EVERY * j) * DIF_BLOCK + AUDIO_PAYLOAD;
+        if (!twelve) {
+          const int base = p->audio_shuffle[q][j];
+          for (int n = 0; n < 36; n++) {
+            const int slot = base + n * p->audio_stride;
+            unsigned v = (unsigned)blk[2 * n] << 8 | blk[2 * n + 1];
+            if (slot >= slots) continue;
+            if (v == 0x8000u) v = 0; /* the format's "no sample" code plays as silence */
+            put_le16(pcm, slot, v);
+          }
+        } else {
+          const int base_l = p->audio_shuffle[q % half][j], base_r = p->audio_shuffle[q % half + half][j];
+          for (int n = 0; n < 24; n++) {
+            const uint8_t *t = blk + 3 * n;
+            const unsigned l = (unsigned)t[0] << 4 | t[2] >> 4, r = (unsigned)t[1] << 4 | (t[2] & 0x0fu);
+            const int slot_l = base_l + n * p->audio_stride, slot_r = base_r + n * p->audio_stride;
+            if (slot_l >= slots) continue; /* the reference tests the left slot only; the right one lies beside it */
+            put_le16(pcm, slot_l, l == 0x800u ? 0u : mi_dv_audio_12to16((uint16_t)l));
+            put_le16(pcm, slot_r, r == 0x800u ? 0u : mi_dv_audio_12to16((uint16_t)r));
           }
         }
-        frame += 16 * 80; /* 15 video DIF blocks + 1 audio DIF block */
       }
     }
-    pcm = ppcm[ipcm++]; /* next pair (50 and 100 Mbps only) */
-    if (!pcm) break;
   }
-  return size / 4;
+  return slots / 2;
 }
 
 int mi_dv_ssyb_pack(const mi_dv_profile *p, const uint8_t *frame, int pack_id, uint8_t pack[5]) {

@@ -12,7 +12,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_SO = os.path.join(ORACLE_DIR, "librtj_oracle.so")
+ORACLE_SO = os.path.join(os.environ.get("MI_SAN_LIBDIR") or ORACLE_DIR, "librtj_oracle.so")  # MI_SAN_LIBDIR: sanitizer build
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "librtjpeg_ref.so")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 

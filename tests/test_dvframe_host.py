@@ -11,7 +11,7 @@ import pytest
 
 from pkg import ROOT
 
-LIB = os.path.join(ROOT, "gmerlin-avdecoder_amd", "lib", "libmi_dvframe.so")
+LIB = os.path.join(os.environ.get("MI_SAN_LIBDIR") or os.path.join(ROOT, "gmerlin-avdecoder_amd", "lib"), "libmi_dvframe.so")  # MI_SAN_LIBDIR: the sanitizer build
 u8p = C.POINTER(C.c_uint8)
 
 

@@ -13,7 +13,7 @@ import pytest
 import rtjlib as R
 from pkg import ROOT
 
-LIB = os.path.join(ROOT, "gmerlin-avdecoder_amd", "lib", "libmi_qtrtj.so")
+LIB = os.path.join(os.environ.get("MI_SAN_LIBDIR") or os.path.join(ROOT, "gmerlin-avdecoder_amd", "lib"), "libmi_qtrtj.so")  # MI_SAN_LIBDIR: the sanitizer build
 
 
 class Sample(C.Structure):
