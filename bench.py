@@ -52,6 +52,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 # what one wave64 vector instruction costs a SIMD while instructions of the slower class are in flight on it, which
 # in k_decode is always (tools/ubench/valu_mix*.hip, valu_stagger.hip; profiles/r02/ubench_valu.txt): 1.80 ns
 VALU_NS_MIXED = 1.80
+VALU_NS_PLAIN = 1.00  # plain 32-bit add / sub / shift / logic (and 16-bit min / max) while no expensive form is in flight
 SIMDS = 256 * 4
 
 
@@ -346,14 +347,19 @@ def main():
         # the vector-issue roof of k_decode: instructions per launch from the PMC profile of these sources
         vi = prof.get("valu_instructions", {}).get("k_decode") if prof and prof["_current"] else None
         if vi and dec["ms"]:
-            need_ms = vi * scale * VALU_NS_MIXED / SIMDS * 1e-6
-            out["roofline_valu"] = {"bound": "valu-issue", "kernel": "k_decode", "instructions_per_launch": int(vi * scale),
-                                    "ns_per_instruction_per_simd": VALU_NS_MIXED, "simds": SIMDS,
-                                    "floor_ms": round(need_ms, 4), "measured_ms": dec["ms"],
-                                    "frac": round(need_ms / dec["ms"], 4),
-                                    "note": "wave64 vector instructions x what one costs a SIMD while expensive-class "
-                                            "instructions are in flight (tools/ubench/valu_mix.hip) / SIMDs; frac = how close "
-                                            "k_decode runs to that roof"}
+            ni = vi * scale
+            out["roofline_valu"] = {
+                "bound": "valu-issue", "kernel": "k_decode", "instructions_per_launch": int(ni), "simds": SIMDS,
+                "measured_ms": dec["ms"], "ns_per_instruction_per_simd": round(dec["ms"] * 1e6 * SIMDS / ni, 3),
+                "ubench_ns_plain": VALU_NS_PLAIN, "ubench_ns_expensive_or_mixed": VALU_NS_MIXED,
+                "floor_ms_all_plain": round(ni * VALU_NS_PLAIN / SIMDS * 1e-6, 4),
+                "floor_ms_all_mixed": round(ni * VALU_NS_MIXED / SIMDS * 1e-6, 4),
+                "frac": round(ni * VALU_NS_PLAIN / SIMDS * 1e-6 / dec["ms"], 4),
+                "note": "wave64 vector instructions (PMC SQ_INSTS_VALU of the same sources) x what one costs a SIMD "
+                        "(tools/ubench/valu_*.hip: 1.0 ns for plain add/sub/shift/logic while no wave of the SIMD has an "
+                        "expensive form in flight, 1.8 ns for everything once one has) / SIMDs.  frac = floor_ms_all_plain / "
+                        "measured: the share of the issue roof (2.4 cycles per instruction) the kernel reaches; it runs between "
+                        "the two floors because its transform passes are ordered to keep plain stretches together"}
         if world == 1 and not a.no_cpu:
             ns = min(n, max(1, a.verify_frames))
             pkts = [dev.d2h(r["d_st"], int(r["pl"][i]), offset=int(r["po"][i])) for i in range(ns)]

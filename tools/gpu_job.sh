@@ -1,5 +1,4 @@
 set -u
-mkdir -p gpurun_out/r02l
-(timeout -k 10 1000 python -m pytest tests/test_bench_launcher.py -m gpu -x -q > gpurun_out/r02l/pytest_bench.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r02l/pytest_bench.log; tail -8 gpurun_out/r02l/pytest_bench.log)
-timeout -k 10 300 python bench.py --config streams4k 2>/dev/null | tee gpurun_out/r02l/bench_streams4k.json
-timeout -k 10 300 python bench.py --config mixed 2>/dev/null | tee gpurun_out/r02l/bench_mixed.json
+bash tools/profile_round.sh r02 2>&1 | tail -5
+python tools/make_traffic.py gpurun_out/r02/pmc_summary.json gpurun_out/r02/traffic.json "r02 (round 2 final kernels)" 4096
+ls gpurun_out/r02
