@@ -1,4 +1,3 @@
 set -u
-bash tools/profile_round.sh r02 2>&1 | tail -5
-python tools/make_traffic.py gpurun_out/r02/pmc_summary.json gpurun_out/r02/traffic.json "r02 (round 2 final kernels)" 4096
-ls gpurun_out/r02
+mkdir -p gpurun_out/r02m
+for rep in 1 2; do for wg in 0 1; do echo "MI_RTJ_DEC_WG=$wg"; MI_RTJ_DEC_WG=$wg bash tools/ab_libs.sh 1 -- product; done; MI_RTJ_DEC_WG=1 bash tools/ab_libs.sh 1 -- lib_wg4.so lib_wg8.so; done 2>&1 | tee gpurun_out/r02m/ab_wg.txt
