@@ -273,7 +273,7 @@ def main():
 
     red_dev = f"cuda:{gpu}" if dist is not None and backend == "nccl" else None
     if a.config != "frames1080":
-        mod = importlib.import_module("gmerlin-avdecoder_amd.bench_configs")
+        mod = importlib.import_module("bench_configs")  # next to this file: bench code, not product (it drives the CPU checker)
         out, mism = mod.run(a, dev, P, shard, dist, red_dev, rank, world, barrier, sync_all, force_dist)
         if rank == 0:
             print(json.dumps(out), flush=True)

@@ -1,4 +1,7 @@
-"""bench.py's workloads for BASELINE.json configs[3] and configs[4] (SURVEY.md section 8d cfg 4 / cfg 5).
+"""bench.py's workloads for BASELINE.json configs[3] and configs[4] (bench code: like bench.py itself it may drive the
+CPU checker under tests/ for its parity checks; the product package never does).
+
+Workloads (SURVEY.md section 8d cfg 4 / cfg 5).
 
 streams4k  one 3840x2160 stream WITH unchanged (0xFF) blocks per rank (stream i -> rank i, shard.streams_for_rank),
            decoded in order through a pipelined session (mi_rtj_pipe_*: the entry points the frame-owning plugin
@@ -16,7 +19,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.abspath(__file__))
 
 
 def _checker():

@@ -7,8 +7,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/mi_rtjpeg.h"
@@ -114,6 +117,12 @@ struct PipeSlot {
   hipEvent_t e_in = nullptr, e_dec = nullptr, e_out = nullptr;
   uint64_t tag = 0;
   int w = 0, h = 0;
+  // hand-over to the session's worker thread (the HIP calls of a packet are made there)
+  size_t len = 0;                   // packet bytes in h_stage
+  const uint8_t* prev = nullptr;    // predecessor's device picture (or none)
+  int issued = 0;                   // 1 once the worker has queued everything up to the copy out (guarded by mu)
+  int rc = 0;                       // what queuing it returned
+  std::string err;
 };
 
 struct mi_rtj_pipe {
@@ -127,6 +136,16 @@ struct mi_rtj_pipe {
   size_t prev_bytes = 0;
   hipStream_t s_in = nullptr, s_out = nullptr;  // kernels run on the instance's stream
   uint64_t submitted = 0, returned = 0;
+  // The thread that submits is what bounds a session (about 50 us of runtime calls per packet next to the 30 us it
+  // takes to copy a 1080p packet into pinned staging), so the two halves run on two threads: the caller copies, a
+  // worker owned by the session makes the HIP calls, in submission order.
+  std::thread worker;
+  std::mutex mu;
+  std::condition_variable cv_work, cv_done;
+  std::vector<int> jobs;      // ring of slot numbers waiting for the worker
+  size_t job_head = 0, job_count = 0;
+  bool stop = false;
+  bool threaded = false;      // MI_RTJ_PIPE_THREAD=1: HIP calls on the worker thread (A/B; off by default)
 };
 
 namespace {
@@ -951,6 +970,64 @@ int mi_rtj_decode_nocopy(mi_rtj_ctx* c, const uint8_t* pkt, size_t len, const ui
 // Pipelined session: the decoder a frame-owning plugin instance reads ahead with (lib/video.c:420-441 nocopy source,
 // lib/video_v4l2_m2m.c:43-131 as the in-tree precedent of a decoder with packets in flight).
 // ---------------------------------------------------------------------------------------------------------------
+namespace {
+// everything of one packet that goes to the device: copy in, kernels, copy out (called on the worker thread, or on
+// the caller's when the session runs without one)
+int pipe_issue(mi_rtj_pipe* q, PipeSlot& sl) {
+  mi_rtj_ctx* c = q->ctx;
+  mi_rtj_plan* p = sl.plan;
+  const size_t fsz = (size_t)sl.w * sl.h * 3 / 2;
+  // (the copy in has a stream of its own: queued between the kernels of successive packets the session ran at
+  // 6-10 K pictures per second instead of 12 K, and the deeper the pipeline the slower — profiles/r02/e2e_*.txt)
+  HIPCHK(c, hipMemcpyAsync(sl.d_stage, sl.h_stage, sizeof(FrameDev) + sl.len, hipMemcpyHostToDevice, q->s_in));
+  HIPCHK(c, hipEventRecord(sl.e_in, q->s_in));
+  HIPCHK(c, hipStreamWaitEvent(c->stream, sl.e_in, 0));
+  // kernels, in submission order on the instance's stream.  Unchanged (0xFF) blocks: k_decode fetches them from the
+  // predecessor's picture (a packet of another size has no predecessor in that sense: its unchanged blocks keep what
+  // the slot's buffer holds, zeros at first)
+  p->prev_pic = sl.prev;
+  const int rc = plan_launch(p, sl.d_stage, sl.d_pic);
+  if (rc != MI_RTJ_OK) return rc;
+  HIPCHK(c, hipEventRecord(sl.e_dec, c->stream));
+  // copy out, on the third stream
+  HIPCHK(c, hipStreamWaitEvent(q->s_out, sl.e_dec, 0));
+  HIPCHK(c, hipMemcpyAsync(sl.h_pic, sl.d_pic, fsz, hipMemcpyDeviceToHost, q->s_out));
+  HIPCHK(c, hipEventRecord(sl.e_out, q->s_out));
+  return MI_RTJ_OK;
+}
+
+void pipe_worker(mi_rtj_pipe* q) {
+  (void)hipSetDevice(q->ctx->device);
+  for (;;) {
+    int idx;
+    {
+      std::unique_lock<std::mutex> lk(q->mu);
+      q->cv_work.wait(lk, [&] { return q->stop || q->job_count > 0; });
+      if (q->job_count == 0) return;  // stop, and nothing left to queue
+      idx = q->jobs[q->job_head];
+    }
+    PipeSlot& sl = q->slot[idx];
+    const int rc = pipe_issue(q, sl);
+    {
+      std::lock_guard<std::mutex> lk(q->mu);
+      sl.rc = rc;
+      if (rc != MI_RTJ_OK) sl.err = q->ctx->err;
+      sl.issued = 1;
+      q->job_head = (q->job_head + 1) % q->jobs.size();
+      q->job_count--;
+    }
+    q->cv_done.notify_all();
+  }
+}
+
+// wait until the worker has nothing left to queue (allocation changes, flush, destroy)
+void pipe_drain_jobs(mi_rtj_pipe* q) {
+  if (!q->threaded) return;
+  std::unique_lock<std::mutex> lk(q->mu);
+  q->cv_done.wait(lk, [&] { return q->job_count == 0; });
+}
+}  // namespace
+
 mi_rtj_pipe* mi_rtj_pipe_create(mi_rtj_ctx* c, int depth, int max_w, int max_h) {
   if (!c || depth < 2 || depth > 64 || max_w < 0 || max_h < 0) {
     fail(c, MI_RTJ_ERR_ARG, "mi_rtj_pipe_create: bad argument (depth 2..64)");
@@ -988,6 +1065,14 @@ mi_rtj_pipe* mi_rtj_pipe_create(mi_rtj_ctx* c, int depth, int max_w, int max_h) 
     mi_rtj_pipe_destroy(q);
     return nullptr;
   }
+  // MI_RTJ_PIPE_THREAD=1: the HIP calls of a packet are made by a worker thread of the session instead of the
+  // caller's.  It frees the caller (which then only copies the packet into staging) but buys no throughput where it
+  // was hoped to: 12,020 against 12,070 pictures per second at 1080p (the copy out bounds the session there, see
+  // DESIGN.md), 20,260 against 18,870 at 320x240 (profiles/r02/e2e_worker_thread.txt).  Off by default.
+  const char* th = getenv("MI_RTJ_PIPE_THREAD");
+  q->threaded = th && atoi(th) != 0;
+  q->jobs.assign((size_t)depth, 0);
+  if (q->threaded) q->worker = std::thread(pipe_worker, q);
   return q;
 }
 
@@ -995,6 +1080,14 @@ void mi_rtj_pipe_destroy(mi_rtj_pipe* q) {
   if (!q) return;
   mi_rtj_ctx* c = q->ctx;
   (void)hipSetDevice(c->device);
+  if (q->worker.joinable()) {
+    {
+      std::lock_guard<std::mutex> lk(q->mu);
+      q->stop = true;
+    }
+    q->cv_work.notify_all();
+    q->worker.join();  // it queues what it still holds, then leaves
+  }
   if (q->s_in) (void)hipStreamSynchronize(q->s_in);
   (void)hipStreamSynchronize(c->stream);
   if (q->s_out) (void)hipStreamSynchronize(q->s_out);
@@ -1037,11 +1130,27 @@ int mi_rtj_pipe_submit(mi_rtj_pipe* q, const uint8_t* pkt, size_t len, uint64_t 
       return fail(c, MI_RTJ_ERR_GEOMETRY, "packet header %dx%d does not match the stream's coded size %dx%d", hw, hh, q->max_w, q->max_h);
   }
   // the slots form a ring: the lent one (if any) sits just before head, then head .. head+count-1, then the free ones
-  PipeSlot& sl = q->slot[(q->head + q->count) % q->depth];
+  const int idx = (q->head + q->count) % q->depth;
+  PipeSlot& sl = q->slot[idx];
   mi_rtj_plan* p = sl.plan;
-  const int rc = fill_frame(c, pkt, 0, (uint32_t)len, 0, 0, &p->h_frames[0]);
+  // (fill_frame and everything below may write the instance's error string and allocate: the worker must be idle
+  // whenever that can happen, i.e. on an error or when a buffer has to grow — not in the steady state)
+  FrameDev f;
+  {
+    FrameDev probe;
+    const int hw = pkt[6] | (pkt[7] << 8), hh = pkt[8] | (pkt[9] << 8);
+    const bool geometry_ok = hw > 0 && hh > 0 && !(hw & 15) && !(hh & 15);
+    const size_t fsz0 = geometry_ok ? (size_t)hw * hh * 3 / 2 : 0;
+    const uint64_t nidx0 = geometry_ok ? ((((uint64_t)(hw / 16) * (hh / 16)) * 6 + 1) + 63) & ~63ull : 0;
+    const uint32_t nchunks0 = (uint32_t)((len - MI_RTJ_HEADER_SIZE + kChunk - 1) / kChunk) + 1u;
+    const bool grows = !geometry_ok || fsz0 > sl.pic_cap || sizeof(FrameDev) + len + kAllocPad > sl.stage_cap ||
+                       nidx0 > p->n_index || nchunks0 > p->n_chunks || (uint64_t)nchunks0 + 1 > p->n_chunk_entries;
+    if (grows) pipe_drain_jobs(q);
+    (void)probe;
+  }
+  const int rc = fill_frame(c, pkt, 0, (uint32_t)len, 0, 0, &f);
   if (rc != MI_RTJ_OK) return rc;
-  FrameDev& f = p->h_frames[0];
+  p->h_frames[0] = f;
   const size_t fsz = (size_t)f.w * f.h * 3 / 2;
   if (fsz > sl.pic_cap) {
     if (sl.d_pic) (void)hipFree(sl.d_pic);
@@ -1078,34 +1187,38 @@ int mi_rtj_pipe_submit(mi_rtj_pipe* q, const uint8_t* pkt, size_t len, uint64_t 
     if (rc2 != MI_RTJ_OK) return rc2;
   }
   // descriptor and packet travel together: one copy in, on its own stream
-  f.data_off = sizeof(FrameDev) + MI_RTJ_HEADER_SIZE;
-  memcpy(sl.h_stage, &f, sizeof(FrameDev));
+  FrameDev& fd = p->h_frames[0];  // plan_alloc_chunks has set its chunk bases
+  fd.data_off = sizeof(FrameDev) + MI_RTJ_HEADER_SIZE;
+  memcpy(sl.h_stage, &fd, sizeof(FrameDev));
   memcpy(sl.h_stage + sizeof(FrameDev), pkt, len);
   p->d_frames = (FrameDev*)sl.d_stage;
-  // (a stream of its own: with the copy in queued between the kernels of successive packets the session ran at
-  // 6-10 K pictures per second instead of 12 K, and the deeper the pipeline the slower — profiles/r02/e2e_*.txt)
-  HIPCHK(c, hipMemcpyAsync(sl.d_stage, sl.h_stage, sizeof(FrameDev) + len, hipMemcpyHostToDevice, q->s_in));
-  HIPCHK(c, hipEventRecord(sl.e_in, q->s_in));
-  HIPCHK(c, hipStreamWaitEvent(c->stream, sl.e_in, 0));
-  // kernels, in submission order on the instance's stream: the picture starts as its predecessor's (0xFF blocks
-  // keep what was there, lib/RTjpeg.c:2704), then the packet is decoded over it
-  // unchanged (0xFF) blocks: k_decode fetches them from the predecessor's picture (a packet of another size has no
-  // predecessor in that sense: its unchanged blocks keep what the slot's buffer holds, zeros at first)
-  p->prev_pic = q->prev_pic && q->prev_bytes == fsz && q->prev_pic != sl.d_pic ? q->prev_pic : nullptr;
-  const int rc3 = plan_launch(p, sl.d_stage, sl.d_pic);
-  if (rc3 != MI_RTJ_OK) return rc3;
-  HIPCHK(c, hipEventRecord(sl.e_dec, c->stream));
-  // copy out, on the third stream
-  HIPCHK(c, hipStreamWaitEvent(q->s_out, sl.e_dec, 0));
-  HIPCHK(c, hipMemcpyAsync(sl.h_pic, sl.d_pic, fsz, hipMemcpyDeviceToHost, q->s_out));
-  HIPCHK(c, hipEventRecord(sl.e_out, q->s_out));
+  sl.len = len;
   sl.tag = tag;
-  sl.w = (int)f.w;
-  sl.h = (int)f.h;
+  sl.w = (int)fd.w;
+  sl.h = (int)fd.h;
+  sl.prev = q->prev_pic && q->prev_bytes == fsz && q->prev_pic != sl.d_pic ? q->prev_pic : nullptr;
   q->prev_pic = sl.d_pic;
   q->prev_bytes = fsz;
   q->count++;
   q->submitted++;
+  if (!q->threaded) {
+    sl.rc = pipe_issue(q, sl);
+    sl.issued = 1;
+    if (sl.rc != MI_RTJ_OK) {  // undo: the packet never went in
+      q->count--;
+      q->submitted--;
+      return sl.rc;
+    }
+    return MI_RTJ_OK;
+  }
+  {
+    std::lock_guard<std::mutex> lk(q->mu);
+    sl.issued = 0;
+    sl.rc = MI_RTJ_OK;
+    q->jobs[(q->job_head + q->job_count) % q->jobs.size()] = idx;
+    q->job_count++;
+  }
+  q->cv_work.notify_one();
   return MI_RTJ_OK;
 }
 
@@ -1116,6 +1229,17 @@ int mi_rtj_pipe_next(mi_rtj_pipe* q, const uint8_t* planes[3], int strides[3], i
   if (q->count == 0) return fail(c, MI_RTJ_ERR_ARG, "mi_rtj_pipe_next: nothing in flight");
   HIPCHK(c, hipSetDevice(c->device));
   PipeSlot& sl = q->slot[q->head];
+  if (q->threaded) {
+    std::unique_lock<std::mutex> lk(q->mu);
+    q->cv_done.wait(lk, [&] { return sl.issued != 0; });
+  }
+  if (sl.rc != MI_RTJ_OK) {  // queuing this packet failed on the worker: it yields no picture
+    const int rc = sl.rc;
+    if (!sl.err.empty()) c->err = sl.err;
+    q->head = (q->head + 1) % q->depth;
+    q->count--;
+    return rc;
+  }
   HIPCHK(c, hipEventSynchronize(sl.e_out));
   if (planes) {
     const size_t ysz = (size_t)sl.w * sl.h;
@@ -1148,6 +1272,7 @@ int mi_rtj_pipe_flush(mi_rtj_pipe* q) {
   mi_rtj_ctx* c = q->ctx;
   HIPCHK(c, hipSetDevice(c->device));
   // work in flight cannot be recalled; it is waited for and forgotten (a seek is rare, a frame takes microseconds)
+  pipe_drain_jobs(q);
   HIPCHK(c, hipStreamSynchronize(q->s_in));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipStreamSynchronize(q->s_out));
