@@ -381,7 +381,8 @@ def main():
                 out["end_to_end"] = {"fps": max((v.get("fps", 0) for v in r2.values() if isinstance(v, dict)), default=0),
                                      "pcie_cap_fps": r2["pcie_cap_fps"], "by_flavour": {k: v for k, v in r2.items() if isinstance(v, dict)},
                                      "note": "one stream, one host thread, through csrc/video_rtjpeg_mi355x.c; fps = the best "
-                                             "flavour (frame-owning with packets in flight); cap = 55 GB/s PCIe / picture bytes"}
+                                             "flavour (frame-owning with packets in flight); cap = what the host link gives one picture-sized pinned copy "
+                                             "at a time (38.4 GB/s for 3.1 MB, tools/pcie_probe.py) / picture bytes"}
             except Exception as exc:  # the harness is a convenience here, not the measurement
                 out["end_to_end"] = {"error": str(exc)[:200]}
         # what a plain streaming copy kernel sustains on this device (read + write), measured now: the second

@@ -25,7 +25,9 @@ def run(width=1920, height=1088, packets=64, repeat=32, depth=4, quality=255, am
     dev.free(d_fr); dev.free(d_st); dev.close()
     subprocess.run(["make", "-C", os.path.join(ROOT, "gmerlin-avdecoder_amd", "csrc")], check=True, capture_output=True)
     out = {"workload": f"{packets} RTjpeg {width}x{height} Q={quality} packets x {repeat} laps, display {width}x{height - 8 if height == 1088 else height}",
-           "pcie_cap_fps": round(55e9 / (width * height * 1.5), 0)}
+           # what the host link gives ONE picture-sized pinned copy at a time (tools/pcie_probe.py, profiles/r02/pcie_probe.json:
+           # 38.4 GB/s for 3.1 MB, 54.6 GB/s for 12.4 MB): the copy out is what bounds a session
+           "pcie_cap_fps": round((38.4e9 if width * height * 1.5 < 6e6 else 54.6e9) / (width * height * 1.5), 0)}
     for fl in flavours:
         exe = os.path.join(ROOT, "gmerlin-avdecoder_amd", "lib", "plugin_harness" + fl)
         env = dict(os.environ, MI_RTJ_DEPTH=str(depth))
