@@ -98,6 +98,7 @@ struct mi_rtj_plan {
   unsigned long long* d_defer = nullptr;   // [k_decode waves][kDecIters]: lanes whose blocks k_decode put off
   size_t cap_defer = 0, defer_words = 0;   // allocated / used by the last launch
   bool defer_on = true;                    // MI_RTJ_DEFER=0 switches the putting-off off (A/B)
+  int rotate = -1;                         // MI_RTJ_ROTATE: 1 / 0 = a k_decode wave takes all three parts of its groups / one part; -1 = by batch size
   const uint8_t* prev_pic = nullptr;       // sessions: where unchanged blocks of this launch are copied from
   std::vector<Timed> ev[MI_RTJ_NUM_KERNELS];  // one pair per launch while profiling
   int launches = 0;
@@ -441,8 +442,14 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
   }
   if ((rc = begin(MI_RTJ_K_DECODE)) != MI_RTJ_OK) return rc;
   // the A/B override is honoured only where it still covers every group
-  const uint32_t dslots = p->dec_slots && p->dec_slots * (uint32_t)kDecIters >= p->max_groups ? p->dec_slots
-                                                                                              : decode_slots(p->max_groups, (uint32_t)p->n);
+  // a wave per (slot, part) or, in batches that still make enough waves that way, per slot: the wave then takes the
+  // three parts of each of its groups in turn and the group's stream bytes cross the fabric once (kernel header)
+  const uint32_t span = p->defer_on ? 1u
+                        : p->rotate >= 0 ? (p->rotate ? 3u : 1u)
+                        : (uint64_t)p->n * p->max_groups >= (uint64_t)kDecRotateMinGroups ? 3u : 1u;
+  const uint32_t dslots = p->dec_slots && p->dec_slots * (uint32_t)kDecIters >= p->max_groups
+                              ? p->dec_slots
+                              : decode_slots(p->max_groups, (uint32_t)p->n, span);
   // groups with many DC-only blocks fill those in and put their other blocks off (one lane mask per wave and
   // iteration, zeroed here); k_decode_list takes the blocks put off, 64 per round.  MI_RTJ_DEFER=0: never put off.
   unsigned long long* defer = nullptr;
@@ -462,8 +469,8 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
     p->defer_words = words;
     HIPCHK(c, hipMemsetAsync(defer, 0, words * sizeof(unsigned long long), c->stream));
   }
-  hipLaunchKernelGGL(k_decode, dim3(dslots * 3u, p->n), dim3(kDecThreads), 0, c->stream, p->d_frames, st, c->d_lut,
-                     p->d_blkoff, (uint8_t*)d_out, defer, p->prev_pic);
+  hipLaunchKernelGGL(k_decode, dim3(span == 3u ? dslots : dslots * 3u, p->n), dim3(kDecThreads), 0, c->stream, p->d_frames,
+                     st, c->d_lut, p->d_blkoff, (uint8_t*)d_out, defer, p->prev_pic, span);
   if (defer)
     hipLaunchKernelGGL(k_decode_list, dim3(dslots * 3u, p->n), dim3(kDecThreads), 0, c->stream, p->d_frames, st, c->d_lut,
                        p->d_blkoff, (uint8_t*)d_out, defer);
@@ -669,6 +676,8 @@ mi_rtj_plan* mi_rtj_plan_create(mi_rtj_ctx* c, int n, const uint8_t* headers, co
     // (off unless asked for: rows with gaps, and the 8-byte row pieces of k_decode_list, cost more in HBM read-modify-
     // write cycles than the idle lanes they save — DESIGN.md; MI_RTJ_DEFER=1 switches it on for plans of kDeferMinGroups)
     p->defer_on = df ? atoi(df) != 0 && (atoi(df) > 1 || (uint64_t)p->n * p->max_groups >= kDeferMinGroups || true) : false;
+    const char* ro = getenv("MI_RTJ_ROTATE");
+    p->rotate = ro ? (atoi(ro) != 0) : -1;
   }
   if (hipSetDevice(c->device) != hipSuccess || plan_alloc_chunks(p) != MI_RTJ_OK) {
     mi_rtj_plan_destroy(p);
@@ -824,10 +833,10 @@ int mi_rtj_plan_deferred(mi_rtj_plan* p, long long* blocks) {
 
 #ifdef MIRTJ_STAMPS
 // diagnostic builds only (not declared in include/mi_rtjpeg.h): cycles per k_decode section since the last call
-extern "C" int mi_rtj_debug_stamps(unsigned long long out[8]) {
+extern "C" int mi_rtj_debug_stamps(unsigned long long out[16]) {
   if (hipDeviceSynchronize() != hipSuccess) return MI_RTJ_ERR_HIP;
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return MI_RTJ_ERR_HIP;
-  unsigned long long zero[8] = {};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return MI_RTJ_ERR_HIP;
+  unsigned long long zero[16] = {};
   if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zero, sizeof zero) != hipSuccess) return MI_RTJ_ERR_HIP;
   return MI_RTJ_OK;
 }

@@ -15,6 +15,7 @@
 
 #include "rtj_common.h"
 #include "rtj_idct_asm.h"
+#include "rtj_idct_pk.h"
 
 namespace mirtj {
 
@@ -365,10 +366,16 @@ __device__ __forceinline__ int med3_i32(int a, int b, int c) {
   return r;
 }
 
-// byte offset, within a lane's transposed coefficient scratch, of zig-zag slot k
+// A lane's coefficient scratch: dword 8 j + r = coefficient (row r, column 2j) | coefficient (row r, column 2j + 1) << 16,
+// so that the 16-byte pieces 2j and 2j + 1 are rows 0-3 and 4-7 of the column pair j, two columns to a register as
+// the packed column pass takes them (rtj_idct_pk.h).  Byte offset of natural index `nat` = 8 row + column:
+__host__ __device__ constexpr int coef_byte(int nat) {
+  return 4 * (((nat & 7) >> 1) * 8 + (nat >> 3)) + 2 * (nat & 1);
+}
+// ... and of zig-zag slot k
 __host__ __device__ constexpr int slot_byte(int k) {
   constexpr uint8_t z[64] = MIRTJ_ZZ_INIT;
-  return 2 * ((z[k] & 7) * 8 + (z[k] >> 3));
+  return coef_byte(z[k]);
 }
 
 constexpr int kDecThreads = 64;
@@ -401,12 +408,14 @@ constexpr bool kForceGenericPaths = false;
 // 5 % faster all the same.  k_decode therefore numbers its blocks slot-major (5.23-5.25 ms whatever the count,
 // v19_block_numbering_ab.txt); the count is kept odd for good measure.
 constexpr uint32_t kDecMinWaves = 65536;
-__host__ __device__ constexpr uint32_t decode_slots(uint32_t groups, uint32_t frames) {
+__host__ __device__ constexpr uint32_t decode_slots(uint32_t groups, uint32_t frames, uint32_t span = 1u) {
   const uint32_t by_iters = (groups + (uint32_t)kDecIters - 1u) / (uint32_t)kDecIters;
-  uint32_t by_batch = (kDecMinWaves + 3u * frames - 1u) / (3u * (frames ? frames : 1u));
+  const uint32_t per_slot = (span == 3u ? 1u : 3u) * (frames ? frames : 1u);  // waves a slot makes
+  uint32_t by_batch = (kDecMinWaves + per_slot - 1u) / per_slot;
   if (by_batch > groups) by_batch = groups;
   return (by_iters > by_batch ? by_iters : by_batch) | 1u;
 }
+constexpr uint32_t kDecRotateMinGroups = 65536;  // groups in a batch from which a wave takes all three parts (span 3)
 constexpr uint32_t kFetchSpan = 72;             // a block's loads stay below its start + this (64 + alignment + look-ahead)
 
 // ---------------------------------------------------------------------------------------
@@ -450,15 +459,16 @@ constexpr int kCoefWords = kDecThreads * kCoefStride / 2;
 #ifndef MIRTJ_DEC_LDS_PAD
 #define MIRTJ_DEC_LDS_PAD 0
 #endif
-constexpr int kDecLdsWords = kCoefWords + kSlotTabN + MIRTJ_DEC_LDS_PAD;
+constexpr int kDecLdsWords = kCoefWords + 2 * kSlotTabN + MIRTJ_DEC_LDS_PAD;  // scratch, luma slot table, chroma slot table
 constexpr int kDecListWords = kDecIters * 64 / 2;  // k_decode_list: one 16-bit (iteration, lane) code per block put off
 
 #ifdef MIRTJ_STAMPS  // diagnostic build: where a wave's time goes (shader cycles per section, summed over all waves)
-__device__ unsigned long long g_stamps[8];
+__device__ unsigned long long g_stamps[16];  // [0..6] luma iterations, [8..14] chroma iterations; [7] waves
 #define MIRTJ_STAMP(i)                                              \
   do {                                                              \
     const unsigned long long t_ = __builtin_amdgcn_s_memtime();     \
-    st_acc[i] += t_ - st_last;                                      \
+    if (chroma) st_c[i] += t_ - st_last;                            \
+    else st_y[i] += t_ - st_last;                                   \
     st_last = t_;                                                   \
   } while (0)
 #else
@@ -473,40 +483,47 @@ template <bool kList>
 __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const FrameDev* __restrict__ frames,
                                             const uint8_t* __restrict__ stream, const QTab* __restrict__ lut,
                                             const uint32_t* __restrict__ blkoff, uint8_t* __restrict__ outbuf,
-                                            unsigned long long* __restrict__ defer, const uint8_t* __restrict__ prev) {
-  uint32_t* s_tab = s_lds + kCoefWords;  // per zig-zag slot: (dequantiser << 16) | scratch byte offset
+                                            unsigned long long* __restrict__ defer, const uint8_t* __restrict__ prev,
+                                            uint32_t span) {
+  // per zig-zag slot: (dequantiser << 16) | scratch byte offset; the luma table, then the chroma table
+  uint32_t* s_tab = s_lds + kCoefWords;
 
   const FrameDev f = frames[blockIdx.y];
-  // slot-major numbering: the three parts of a slot are dispatched one after the other and (workgroups are
-  // dealt round-robin to the 8 XCDs) land on different XCDs — see decode_slots()
-  const uint32_t slots = gridDim.x / 3u;
-  const uint32_t slot = blockIdx.x / 3u, part = blockIdx.x - slot * 3u;
+  // span == 1: a wave owns ONE part of its groups; grid.x = 3 * slots, numbered slot-major: the three parts of a slot
+  // are dispatched one after the other and (workgroups are dealt round-robin to the 8 XCDs) land on different XCDs —
+  // see decode_slots().  span == 3: a wave takes all three parts of its groups in turn (grid.x = slots), so a group's
+  // stream bytes and block offsets come over the fabric once instead of three times.
+  const bool rot = !kList && span == 3u;  // wave-uniform
+  const uint32_t slots = rot ? gridDim.x : gridDim.x / 3u;
+  const uint32_t slot = rot ? blockIdx.x : blockIdx.x / 3u, part0 = rot ? 0u : blockIdx.x - slot * 3u;
   const uint32_t ngroups = (f.nmb + (uint32_t)kMbPerGroup - 1u) / (uint32_t)kMbPerGroup;
   if (slot >= ngroups) return;
 #ifdef MIRTJ_EXP_ONLY_PART  // experiment builds (tools/pmc_parts.sh): 2 = only the chroma part works, 0 = only the luma parts
-  if ((MIRTJ_EXP_ONLY_PART == 2) != (part == 2u)) return;
+  if (!rot && (MIRTJ_EXP_ONLY_PART == 2) != (part0 == 2u)) return;
 #endif
   const int lane = threadIdx.x;
   const uint32_t* off = blkoff + f.blk_base;
   const QTab& qt = lut[f.qidx];
-  const int chroma = part == 2u;
   {
     const int nat = c_zz[lane];
-    const int q = chroma ? qt.ciqt[nat] : qt.liqt[nat];  // 0 .. 13984
-    s_tab[lane] = ((uint32_t)q << 16) | (uint32_t)(2 * ((nat & 7) * 8 + (nat >> 3)));
-    if (lane < kSlotTabN - 64) s_tab[64 + lane] = 128u;  // finished: multiplier 0, scratch slot 64 (write-only)
+    const uint32_t where = (uint32_t)coef_byte(nat);
+    s_tab[lane] = ((uint32_t)qt.liqt[nat] << 16) | where;  // dequantisers: 0 .. 13984
+    s_tab[kSlotTabN + lane] = ((uint32_t)qt.ciqt[nat] << 16) | where;
+    if (lane < kSlotTabN - 64) {  // finished: multiplier 0, scratch slot 64 (write-only)
+      s_tab[64 + lane] = 128u;
+      s_tab[kSlotTabN + 64 + lane] = 128u;
+    }
   }
   __syncthreads();  // one wave: orders the table write before the lanes' reads
-  const uint32_t bt8 = (uint32_t)(chroma ? qt.cb8 : qt.lb8);
   const uint32_t my_a = lds_address(s_lds) + (uint32_t)lane * (uint32_t)(kCoefStride * 2);
-  const uint32_t tab_a = lds_address(s_tab);
-  const int ca_end = (int)tab_a + 4 * 64;  // slot counter (see below) of a finished block
   const int k63 = 63;
   const uint4* my = (const uint4*)((const uint8_t*)s_lds + (size_t)lane * (kCoefStride * 2));
-
-  // ---- which block of a group is mine (k_decode; k_decode_list looks both up per round) ----
-  const uint32_t dmb_own = chroma ? (uint32_t)(lane & 31) : (uint32_t)(lane >> 1);
-  const uint32_t kblk_own = chroma ? 4u + (uint32_t)(lane >> 5) : 2u * part + (uint32_t)(lane & 1);
+  // what depends on the part in hand (wave-uniform; set at the top of every iteration)
+  int chroma = part0 == 2u;
+  const uint32_t bt8_y = (uint32_t)qt.lb8, bt8_c = (uint32_t)qt.cb8;
+  uint32_t bt8 = chroma ? bt8_c : bt8_y;
+  uint32_t tab_a = lds_address(s_tab) + (chroma ? 4u * (uint32_t)kSlotTabN : 0u);
+  int ca_end = (int)tab_a + 4 * 64;  // slot counter (see below) of a finished block
   const uint8_t* data = stream + f.data_off;
   unsigned long long* my_defer =
       defer ? defer + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)kDecIters : nullptr;
@@ -533,38 +550,47 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
   }
   // iteration `it` of this wave: which group, which block of it, and is there one (per lane)
   struct Src {
-    uint32_t grp, dmb, kblk, mb;
+    uint32_t grp, dmb, kblk, mb, part;  // part: wave-uniform
     bool valid;
   };
   auto source = [&](uint32_t it) -> Src {
     Src r;
     if (!kList) {
-      r.grp = slot + it * slots;
-      r.dmb = dmb_own;
-      r.kblk = kblk_own;
+      uint32_t g = it;
+      r.part = part0;
+      if (rot) {
+        g = it / 3u;
+        r.part = it - 3u * g;
+      }
+      r.grp = slot + g * slots;
+      r.dmb = r.part == 2u ? (uint32_t)(lane & 31) : (uint32_t)(lane >> 1);
+      r.kblk = r.part == 2u ? 4u + (uint32_t)(lane >> 5) : 2u * r.part + (uint32_t)(lane & 1);
       r.mb = r.grp * (uint32_t)kMbPerGroup + r.dmb;
-      r.valid = it < (uint32_t)kDecIters && r.mb < f.nmb;
+      r.valid = g < (uint32_t)kDecIters && r.mb < f.nmb;
     } else {
+      r.part = part0;
       const uint32_t e = it * 64u + (uint32_t)lane;
       r.valid = e < n_listed;
       const uint32_t code = r.valid ? (uint32_t)s_list[e] : 0u;
       const uint32_t ls = code & 63u;
       r.grp = slot + (code >> 6) * slots;
       r.dmb = chroma ? ls & 31u : ls >> 1;
-      r.kblk = chroma ? 4u + (ls >> 5) : 2u * part + (ls & 1u);
+      r.kblk = chroma ? 4u + (ls >> 5) : 2u * part0 + (ls & 1u);
       r.mb = r.grp * (uint32_t)kMbPerGroup + r.dmb;
     }
     return r;
   };
   auto more_after = [&](uint32_t it) -> bool {  // wave-uniform: is there an iteration it + 1
-    return kList ? (it + 1u) * 64u < n_listed : it + 1u < (uint32_t)kDecIters && slot + (it + 1u) * slots < ngroups;
+    if (kList) return (it + 1u) * 64u < n_listed;
+    const uint32_t g = rot ? (it + 1u) / 3u : it + 1u;
+    return g < (uint32_t)kDecIters && slot + g * slots < ngroups;
   };
 
   // ---- "DC only" blocks as the encoder writes them: DC, bt8 zero bytes, then one run over the other 63 - bt8 slots
   // (RTjpeg_b2s, lib/RTjpeg.c:109-155: a run is the byte 63 + length).  Such a block is the pixel
   // clamp((int16(DC * q0) + 4) >> 3) 64 times over: every term of both passes but the DC path is zero
   // (lib/RTjpeg.c:2223-2238 is the reference's own shortcut for it).  The test reads the block's first 16 bytes.
-  const bool dc_test = !kList && my_defer != nullptr && bt8 <= 14u;
+  const bool dc_test = !kList && !rot && my_defer != nullptr && bt8 <= 14u;  // (the host never asks for both)
   unsigned long long dcm_lo = 0, dcm_hi = 0, dcp_lo = 0, dcp_hi = 0;  // byte masks / expected bytes, wave-uniform
   {
     const uint32_t nb1 = bt8 + 2u;  // bytes 0 .. bt8+1 take part (byte 0, DC, is masked out again)
@@ -575,7 +601,7 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
     if (bt8 + 1u < 8u) dcp_lo = run << (8u * (bt8 + 1u));
     else dcp_hi = run << (8u * (bt8 + 1u - 8u));
   }
-  const int q_dc = chroma ? qt.ciqt[0] : qt.liqt[0];
+  const int q_dc = chroma ? qt.ciqt[0] : qt.liqt[0];  // (dc_test: the part is fixed)
 
   // the dword that holds stream byte `p` and the four after it, bytes at or past data_len read as 0;
   // `inside`: every lane's loads are known to lie inside the packet
@@ -625,8 +651,8 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
   // that does not slow the transform's cheap stretches down (a 64-bit pointer step does, rtj_idct_asm.h).  Offsets
   // stay below 2^32: the luma plane of the largest picture the header can describe has 65520^2 bytes.
   const size_t ysz = (size_t)f.w * f.h;
-  const size_t plane_off = f.out_off + (chroma ? ysz : (size_t)0);  // wave-uniform
-  const uint32_t stride = chroma ? f.w >> 1 : f.w;
+  size_t plane_off = f.out_off + (chroma ? ysz : (size_t)0);  // wave-uniform
+  uint32_t stride = chroma ? f.w >> 1 : f.w;
   auto block_offset = [&](uint32_t grp, uint32_t dmb, uint32_t kblk, uint32_t mb) -> uint32_t {
     // macroblock coordinates without a per-lane division: one scalar division for the group's
     // first macroblock, then at most one row wrap per lane when rows are at least a group wide
@@ -646,15 +672,18 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
   };
 
 #ifdef MIRTJ_STAMPS
-  unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
+  unsigned long long st_y[7] = {0, 0, 0, 0, 0, 0, 0}, st_c[7] = {0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
 #endif
-  Src s0 = source(0u), s1 = source(1u);
+  // (which block a lane has in an iteration is worked out afresh where it is needed — a handful of instructions —
+  // instead of being carried from iteration to iteration in vector registers: the register count decides how many
+  // waves a SIMD holds)
+  const Src s0 = source(0u), s1 = source(1u);
   uint32_t pos0 = off[s0.valid ? 6u * s0.mb + s0.kblk : 0u];  // block start relative to the first data byte
   uint32_t pos_n = off[s1.valid ? 6u * s1.mb + s1.kblk : 0u];  // the same for the wave's next iteration
   pos0 = s0.valid ? pos0 : 0u;
   bool inside = !kForceGenericPaths && __all(pos0 + kFetchSpan <= f.data_len);  // wave-uniform
   Bytes cur = fetch(pos0, inside, 9);  // 32 bytes (+ alignment): all of most blocks
-  bool try_lo = true;  // wave-uniform: test this wave's blocks for "low 4x4 only" until a test fails
+  bool try_lo_y = true, try_lo_c = true;  // wave-uniform: test this wave's luma / chroma blocks for "low 4x4 only" until a test fails
   // the first group's loads are waited for here, not inside the loop: a wait at the top of the loop would be a
   // wait for everything in flight (it could not tell the first entry from the back edge), the row stores included
   asm volatile("" ::"v"(cur.d[0]), "v"(cur.d[1]), "v"(cur.d[2]), "v"(cur.d[3]), "v"(cur.d[4]), "v"(cur.d[5]),
@@ -663,9 +692,18 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
   MIRTJ_STAMP(0);  // prologue: descriptor, table, first offsets and bytes
   for (uint32_t it = 0;; it++) {
     const bool have_n = more_after(it);  // wave-uniform
-    const bool valid = s0.valid, valid_n = have_n && s1.valid;
+    const Src s0 = source(it);
+    const bool valid = s0.valid, valid_n = have_n && source(it + 1u).valid;
     const uint32_t grp = s0.grp, dmb = s0.dmb, kblk = s0.kblk, mb = s0.mb;
     pos_n = valid_n ? pos_n : 0u;
+    if (rot) {  // the part in hand
+      chroma = s0.part == 2u;
+      bt8 = chroma ? bt8_c : bt8_y;
+      tab_a = lds_address(s_tab) + (chroma ? 4u * (uint32_t)kSlotTabN : 0u);
+      ca_end = (int)tab_a + 4 * 64;
+      plane_off = f.out_off + (chroma ? ysz : (size_t)0);
+      stride = chroma ? f.w >> 1 : f.w;
+    }
 
     const uint32_t sh = (uint32_t)((uintptr_t)(data + pos0) & 3u);
     uint32_t d0 = cur.d[0], d1 = cur.d[1], d2 = cur.d[2], d3 = cur.d[3], d4 = cur.d[4];
@@ -793,19 +831,17 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
     typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
     u32x4_t nb0, nb1;
     uint32_t nb2, pos_nn;
-    Bytes near_end;  // the next group's bytes when they were fetched with masks (end of the packet)
     bool inside_n = false;
-    Src s2 = s1;
     if (have_n) {
       inside_n = !kForceGenericPaths && __all(pos_n + kFetchSpan <= f.data_len);
-      s2 = source(it + 2u);
+      const Src s2 = source(it + 2u);
       const uint32_t* offp = off + (s2.valid ? 6u * s2.mb + s2.kblk : 0u);
       const uint8_t* g = data + pos_n;
       const uint32_t* g4 = (const uint32_t*)(g - ((uintptr_t)g & 3u));
-      if (!inside_n) {  // near the packet's end: masked loads, waited for at once (rare); the hand-issued loads
-        near_end = fetch(pos_n, false, 9);  // below then read this packet's descriptor (64 valid bytes) instead
-        g4 = (const uint32_t*)(frames + blockIdx.y);
-      }
+      // near the packet's end (rare) the bytes are fetched with masks, behind the wait at the end of this iteration —
+      // fetched here they would occupy nine registers across the transform on every path; the hand-issued loads
+      // below then read this packet's descriptor (64 valid bytes) instead
+      if (!inside_n) g4 = (const uint32_t*)(frames + blockIdx.y);
       // one block, issued on every path that has a next group: its results take part in no selection before the
       // wait (a selection could be a register copy, and a copy of a register that is still being filled is wrong)
       asm volatile(
@@ -820,22 +856,20 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
 
     // ---- does any block of the wave reach outside the low 4x4?  (columns 4-7, rows 4-7) ----
     bool lo = false;
+    const bool try_lo = chroma ? try_lo_c : try_lo_y;
     if (try_lo) {  // wave-uniform
       uint32_t hi = 0;
       if (live_blk) {
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-          const uint2 q = *(const uint2*)((const uint8_t*)my + 16 * c + 8);
-          hi |= q.x | q.y;
-        }
-#pragma unroll
-        for (int c = 4; c < 8; c++) {
-          const uint4 q = my[c];
+        for (int i = 0; i < 8; i++) {
+          if (i == 0 || i == 2) continue;  // rows 0-3 of columns 0-3
+          const uint4 q = my[i];
           hi |= q.x | q.y | q.z | q.w;
         }
       }
       lo = !__any(hi != 0u);
-      try_lo = lo;
+      if (chroma) try_lo_c = lo;
+      else try_lo_y = lo;
     }
 
     MIRTJ_STAMP(2);  // look-ahead loads issued, low-4x4 test
@@ -855,6 +889,8 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
         off32 += stride_v;
       };
       const IdctK K{362, 473, -669, 277, 128, 235};
+      const IdctPK KP = idct_pk_constants();
+      auto half16 = [](uint32_t w, int odd) -> int { return odd ? (int)w >> 16 : (int)(int16_t)(w & 0xFFFFu); };
       auto put_row = [&](const int (&y)[8]) {
         uint2 o;
         // three shift-or instructions per four pixels, spelled out: the compiler's own choice for
@@ -883,54 +919,74 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
           }
         }
       } else if (lo) {
-        uint2 ql[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) ql[c] = *(const uint2*)((const uint8_t*)my + 16 * c);
+        // rows 0-3 of the column pairs (0, 1) and (2, 3)
+        const uint4 qa = my[0], qb = my[2];
         // anything in row 3 or column 3?  (the lanes of this branch: those with a live block)
-        const uint32_t t3 = ql[3].x | ql[3].y | ((ql[0].y | ql[1].y | ql[2].y) & 0xFFFF0000u);
+        const uint32_t t3 = qa.w | qb.w | ((qb.x | qb.y | qb.z) & 0xFFFF0000u);
         if (!__any(t3 != 0u)) {
           // ---- three-input transform: columns 0-2 in, rows of three in ----
-          int ws[8][3];
-#if MIRTJ_ASM_IDCT
+#if MIRTJ_PK_IDCT
+          const bool fits = __all(pk_range_lo3(qa, qb, KP));
+          MIRTJ_STAMP(5);  // coordinates, scratch reads, 16-bit range test
+          if (fits) {
+            // two columns, then two rows, to a register (rtj_idct_pk.h)
+            uint32_t ya[8], yb[8];
+            idct8_pk_lo3_col<true>(qa.x, qa.y, qa.z, ya, KP);   // columns 0, 1
+            idct8_pk_lo3_col<false>(qb.x, qb.y, qb.z, yb, KP);  // columns 2, (3: zero)
+#pragma unroll
+            for (int r = 0; r < 8; r += 2) {
+              uint2 o0, o1;
+              idct8_pk_lo3_row_px(ya[r], ya[r + 1], yb[r], yb[r + 1], o0, o1, KP);
+              put_packed(o0);
+              put_packed(o1);
+            }
+          } else
+#endif
           {
-            int y[8];
-            idct8_lo3_col<true>(ql[0].x, ql[0].y, y, K);
+            int ws[8][3];
+#if MIRTJ_ASM_IDCT
+            {
+              int y[8];
+              idct8_lo3_col<true, false>(qa.x, qa.y, qa.z, y, K);
 #pragma unroll
-            for (int r = 0; r < 8; r++) ws[r][0] = y[r];
+              for (int r = 0; r < 8; r++) ws[r][0] = y[r];
+              idct8_lo3_col<false, true>(qa.x, qa.y, qa.z, y, K);
 #pragma unroll
-            for (int c = 1; c < 3; c++) {
-              idct8_lo3_col<false>(ql[c].x, ql[c].y, y, K);
+              for (int r = 0; r < 8; r++) ws[r][1] = y[r];
+              idct8_lo3_col<false, false>(qb.x, qb.y, qb.z, y, K);
+#pragma unroll
+              for (int r = 0; r < 8; r++) ws[r][2] = y[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) put_packed(idct8_lo3_row_px(ws[r][0], ws[r][1], ws[r][2], K));
+#else
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+              const uint4& q = c < 2 ? qa : qb;
+              int x0 = half16(q.x, c & 1);
+              const int x1 = half16(q.y, c & 1), x2 = half16(q.z, c & 1);
+              if (c == 0) x0 += 4;  // DESCALE's rounding term, carried through both linear DC paths
+              int y[8];
+              idct8_lo3(x0, x1, x2, y);
 #pragma unroll
               for (int r = 0; r < 8; r++) ws[r][c] = y[r];
             }
-          }
 #pragma unroll
-          for (int r = 0; r < 8; r++) put_packed(idct8_lo3_row_px(ws[r][0], ws[r][1], ws[r][2], K));
-#else
-#pragma unroll
-          for (int c = 0; c < 3; c++) {
-            int x0 = (int)(int16_t)(ql[c].x & 0xFFFFu);
-            const int x1 = (int)ql[c].x >> 16, x2 = (int)(int16_t)(ql[c].y & 0xFFFFu);
-            if (c == 0) x0 += 4;  // DESCALE's rounding term, carried through both linear DC paths
-            int y[8];
-            idct8_lo3(x0, x1, x2, y);
-#pragma unroll
-            for (int r = 0; r < 8; r++) ws[r][c] = y[r];
-          }
-#pragma unroll
-          for (int r = 0; r < 8; r++) {
-            int y[8];
-            idct8_lo3(ws[r][0], ws[r][1], ws[r][2], y);
-            put_row(y);
-          }
+            for (int r = 0; r < 8; r++) {
+              int y[8];
+              idct8_lo3(ws[r][0], ws[r][1], ws[r][2], y);
+              put_row(y);
+            }
 #endif
+          }
         } else {
           // ---- four-input transform: columns 0-3 in, rows of four in ----
           int ws[8][4];
 #pragma unroll
           for (int c = 0; c < 4; c++) {
-            int x0 = (int)(int16_t)(ql[c].x & 0xFFFFu);
-            const int x1 = (int)ql[c].x >> 16, x2 = (int)(int16_t)(ql[c].y & 0xFFFFu), x3 = (int)ql[c].y >> 16;
+            const uint4& q = c < 2 ? qa : qb;
+            int x0 = half16(q.x, c & 1);
+            const int x1 = half16(q.y, c & 1), x2 = half16(q.z, c & 1), x3 = half16(q.w, c & 1);
             if (c == 0) x0 += 4;  // DESCALE's rounding term, carried through both linear DC paths
             int y[8];
             idct8_lo(x0, x1, x2, x3, y);
@@ -945,46 +1001,91 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
           }
         }
       } else {
-        // ---- column pass: column c of the block is the c-th 16-byte piece of the scratch ----
-        int ws[8][8];
+        bool packed = false;
+#if MIRTJ_PK_IDCT
+        uint4 q[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) q[i] = my[i];
+        packed = __all(pk_range_full(q, KP));  // wave-uniform
+        MIRTJ_STAMP(5);  // coordinates, scratch reads, 16-bit range test
+        if (packed) {
+          // ---- column pass on the four column pairs, as they lie in the scratch (rtj_idct_pk.h) ----
+          uint32_t yy[4][8];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            uint32_t x[8] = {q[2 * j].x,     q[2 * j].y,     q[2 * j].z,     q[2 * j].w,
+                             q[2 * j + 1].x, q[2 * j + 1].y, q[2 * j + 1].z, q[2 * j + 1].w};
+            if (j == 0) idct8_pk_col<true>(x, KP);
+            else idct8_pk_col<false>(x, KP);
+#pragma unroll
+            for (int r = 0; r < 8; r++) yy[j][r] = x[r];
+          }
+          // ---- row pass on the four row pairs + scatter ----
+#pragma unroll
+          for (int r = 0; r < 8; r += 2) {
+            uint2 o0, o1;
+            uint32_t ya[4] = {yy[0][r], yy[1][r], yy[2][r], yy[3][r]};
+            uint32_t yb[4] = {yy[0][r + 1], yy[1][r + 1], yy[2][r + 1], yy[3][r + 1]};
+            idct8_pk_row_px(ya, yb, o0, o1, KP);
+            put_packed(o0);
+            put_packed(o1);
+          }
+        }
+#endif
+        if (!packed) {
+          // ---- column pass: column c is one half of the 16-byte pieces c & ~1 (rows 0-3) and (c & ~1) + 1 (rows 4-7) ----
+          // Two rounds, rows 0-3 and rows 4-7, each with a column pass of its own: this path is the rare one (a block
+          // outside the 16-bit budget), and 32 + 32 registers of column results are what the kernel's register count —
+          // and with it the waves per SIMD of EVERY path — would be sized for.  (The scratch is read again, through
+          // an address the compiler cannot tell from the one above, or the 32 registers of the range test stay alive
+          // as well.)
+          uint32_t again = (uint32_t)lane * (uint32_t)(kCoefStride * 2);
+          asm volatile("" : "+v"(again));
+          const uint4* my = (const uint4*)((const uint8_t*)s_lds + again);
 #if MIRTJ_ASM_IDCT
-        {
-          int y[8];
-          idct8_col<true>(my[0], y, K);
 #pragma unroll
-          for (int r = 0; r < 8; r++) ws[r][0] = y[r];
+          for (int half = 0; half < 2; half++) {
+            int ws[4][8];
+            int y[8];
+            idct8_col<true, false>(my[0], my[1], y, K);
 #pragma unroll
-          for (int c = 1; c < 8; c++) {
-            idct8_col<false>(my[c], y, K);
+            for (int r = 0; r < 4; r++) ws[r][0] = y[4 * half + r];
+#pragma unroll
+            for (int c = 1; c < 8; c++) {
+              if (c & 1) idct8_col<false, true>(my[c - 1], my[c], y, K);
+              else idct8_col<false, false>(my[c], my[c + 1], y, K);
+#pragma unroll
+              for (int r = 0; r < 4; r++) ws[r][c] = y[4 * half + r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+              put_packed(idct8_row_px(ws[r][0], ws[r][1], ws[r][2], ws[r][3], ws[r][4], ws[r][5], ws[r][6], ws[r][7], K));
+            asm volatile("" : "+v"(again));  // (keeps the second round's column pass from being merged into the first)
+            my = (const uint4*)((const uint8_t*)s_lds + again);
+          }
+#else
+          int ws[8][8];
+#pragma unroll
+          for (int c = 0; c < 8; c++) {
+            const uint4 a = my[c & ~1], b = my[(c & ~1) + 1];
+            int x0 = half16(a.x, c & 1);
+            const int x1 = half16(a.y, c & 1), x2 = half16(a.z, c & 1), x3 = half16(a.w, c & 1);
+            const int x4 = half16(b.x, c & 1), x5 = half16(b.y, c & 1), x6 = half16(b.z, c & 1), x7 = half16(b.w, c & 1);
+            if (c == 0) x0 += 4;  // DESCALE's rounding term, carried through both linear DC paths
+            int y[8];
+            idct8(x0, x1, x2, x3, x4, x5, x6, x7, y);
 #pragma unroll
             for (int r = 0; r < 8; r++) ws[r][c] = y[r];
           }
-        }
+          // ---- row pass + scatter ----
 #pragma unroll
-        for (int r = 0; r < 8; r++)
-          put_packed(idct8_row_px(ws[r][0], ws[r][1], ws[r][2], ws[r][3], ws[r][4], ws[r][5], ws[r][6], ws[r][7], K));
-#else
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-          const uint4 q = my[c];
-          int x0 = (int)(int16_t)(q.x & 0xFFFFu), x1 = (int)q.x >> 16;
-          const int x2 = (int)(int16_t)(q.y & 0xFFFFu), x3 = (int)q.y >> 16;
-          const int x4 = (int)(int16_t)(q.z & 0xFFFFu), x5 = (int)q.z >> 16;
-          const int x6 = (int)(int16_t)(q.w & 0xFFFFu), x7 = (int)q.w >> 16;
-          if (c == 0) x0 += 4;  // DESCALE's rounding term, carried through both linear DC paths
-          int y[8];
-          idct8(x0, x1, x2, x3, x4, x5, x6, x7, y);
-#pragma unroll
-          for (int r = 0; r < 8; r++) ws[r][c] = y[r];
-        }
-        // ---- row pass + scatter ----
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-          int y[8];
-          idct8(ws[r][0], ws[r][1], ws[r][2], ws[r][3], ws[r][4], ws[r][5], ws[r][6], ws[r][7], y);
-          put_row(y);
-        }
+          for (int r = 0; r < 8; r++) {
+            int y[8];
+            idct8(ws[r][0], ws[r][1], ws[r][2], ws[r][3], ws[r][4], ws[r][5], ws[r][6], ws[r][7], y);
+            put_row(y);
+          }
 #endif
+        }
       }
     }
     MIRTJ_STAMP(3);  // coordinates, transform, row stores
@@ -1015,24 +1116,26 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
           : "scc", "memory");
     }
     MIRTJ_STAMP(4);  // the counted wait for the look-ahead loads
-    s0 = s1;
-    s1 = s2;
     pos0 = pos_n;
-    pos_n = pos_nn;
+    // a copy of our own, BEHIND the wait: left to the compiler, the loop-carried register of pos_n may be filled by a
+    // copy it places in front of the wait block (tools/check_async_loads.py found exactly that)
+    asm volatile("v_mov_b32 %0, %1" : "=v"(pos_n) : "v"(pos_nn));
     if (inside_n) {
       cur.d[0] = nb0.x; cur.d[1] = nb0.y; cur.d[2] = nb0.z; cur.d[3] = nb0.w;
       cur.d[4] = nb1.x; cur.d[5] = nb1.y; cur.d[6] = nb1.z; cur.d[7] = nb1.w;
       cur.d[8] = nb2;
     } else {
-      cur = near_end;
+      cur = fetch(pos0, false, 9);
     }
     inside = inside_n;
   }
 #ifdef MIRTJ_STAMPS
   if (lane == 0) {
-    const int base = chroma ? 0 : 0;
-    for (int i = 0; i < 5; i++) atomicAdd(&g_stamps[base + i], st_acc[i]);
-    atomicAdd(&g_stamps[5], 1ull);
+    for (int i = 0; i < 7; i++) {
+      atomicAdd(&g_stamps[i], st_y[i]);
+      atomicAdd(&g_stamps[8 + i], st_c[i]);
+    }
+    atomicAdd(&g_stamps[7], 1ull);
   }
 #endif
 }
@@ -1046,9 +1149,9 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
                                                          const uint32_t* __restrict__ blkoff,
                                                          uint8_t* __restrict__ outbuf,
                                                          unsigned long long* __restrict__ defer,
-                                                         const uint8_t* __restrict__ prev) {
+                                                         const uint8_t* __restrict__ prev, uint32_t span) {
   __shared__ __attribute__((aligned(16))) uint32_t s_lds[kDecLdsWords];
-  decode_wave<false>(s_lds, frames, stream, lut, blkoff, outbuf, defer, prev);
+  decode_wave<false>(s_lds, frames, stream, lut, blkoff, outbuf, defer, prev, span);
 }
 
 // k_decode_list: same grid; the wave (slot, part, frame) takes the blocks its k_decode twin put off, 64 per round —
@@ -1061,7 +1164,7 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode_list(co
                                                               uint8_t* __restrict__ outbuf,
                                                               unsigned long long* __restrict__ defer) {
   __shared__ __attribute__((aligned(16))) uint32_t s_lds[kDecLdsWords + kDecListWords];
-  decode_wave<true>(s_lds, frames, stream, lut, blkoff, outbuf, defer, nullptr);
+  decode_wave<true>(s_lds, frames, stream, lut, blkoff, outbuf, defer, nullptr, 1u);
 }
 
 // set bits of a word array (mi_rtj_plan_deferred: blocks put off by the last k_decode)

@@ -160,20 +160,21 @@ __device__ __forceinline__ uint2 idct8_row_px(int x0, int x1, int x2, int x3, in
   return make_uint2(o0, o1);
 }
 
-// ---- column pass from the scratch: q = (x0 | x1 << 16, x2 | x3 << 16, x4 | x5 << 16, x6 | x7 << 16), int16 each.
-// The first stage reads the halves directly (SDWA: expensive, so it opens the cluster).  kDc: column 0 carries
-// DESCALE's rounding term, +4 on the DC coefficient, through both of its linear paths. ----
-#define MIRTJ_SDWA2(OP, D, A, ASEL, B, BSEL) \
-  OP " " D ", sext(" A "), sext(" B ") dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" ASEL " src1_sel:" BSEL "\n\t"
-#define MIRTJ_COL_HEAD                                                                                         \
-  MIRTJ_SDWA2("v_add_u32_sdwa", "%[t0]", "%[qx]", "WORD_0", "%[qz]", "WORD_0") /* s04 = x0 + x4 */            \
-  MIRTJ_SDWA2("v_sub_u32_sdwa", "%[x0]", "%[qx]", "WORD_0", "%[qz]", "WORD_0") /* d04 = x0 - x4 */            \
-  MIRTJ_SDWA2("v_add_u32_sdwa", "%[x4]", "%[qy]", "WORD_0", "%[qw]", "WORD_0") /* s26 = x2 + x6 */            \
-  MIRTJ_SDWA2("v_sub_u32_sdwa", "%[x2]", "%[qy]", "WORD_0", "%[qw]", "WORD_0") /* x2 - x6 */                  \
-  MIRTJ_SDWA2("v_add_u32_sdwa", "%[x6]", "%[qz]", "WORD_1", "%[qy]", "WORD_1") /* s53 = x5 + x3 */            \
-  MIRTJ_SDWA2("v_sub_u32_sdwa", "%[x5]", "%[qz]", "WORD_1", "%[qy]", "WORD_1") /* d53 = x5 - x3 */            \
-  MIRTJ_SDWA2("v_add_u32_sdwa", "%[x3]", "%[qx]", "WORD_1", "%[qw]", "WORD_1") /* s17 = x1 + x7 */            \
-  MIRTJ_SDWA2("v_sub_u32_sdwa", "%[x1]", "%[qx]", "WORD_1", "%[qw]", "WORD_1") /* d17 = x1 - x7 */            \
+// ---- column pass from the scratch: a = rows 0-3, b = rows 4-7 of a column PAIR, one row to a dword, the even
+// column in the low half (rtj_decode_kernels.h, coef_byte); kOdd picks the column.  The first stage reads the halves
+// directly (SDWA: expensive, so it opens the cluster).  kDc: column 0 carries DESCALE's rounding term, +4 on the
+// DC coefficient, through both of its linear paths. ----
+#define MIRTJ_SDWA2(OP, D, A, B, SEL) \
+  OP " " D ", sext(" A "), sext(" B ") dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SEL " src1_sel:" SEL "\n\t"
+#define MIRTJ_COL_HEAD(SEL)                                                                         \
+  MIRTJ_SDWA2("v_add_u32_sdwa", "%[t0]", "%[ax]", "%[bx]", SEL) /* s04 = x0 + x4 */                 \
+  MIRTJ_SDWA2("v_sub_u32_sdwa", "%[x0]", "%[ax]", "%[bx]", SEL) /* d04 = x0 - x4 */                 \
+  MIRTJ_SDWA2("v_add_u32_sdwa", "%[x4]", "%[az]", "%[bz]", SEL) /* s26 = x2 + x6 */                 \
+  MIRTJ_SDWA2("v_sub_u32_sdwa", "%[x2]", "%[az]", "%[bz]", SEL) /* x2 - x6 */                       \
+  MIRTJ_SDWA2("v_add_u32_sdwa", "%[x6]", "%[by]", "%[aw]", SEL) /* s53 = x5 + x3 */                 \
+  MIRTJ_SDWA2("v_sub_u32_sdwa", "%[x5]", "%[by]", "%[aw]", SEL) /* d53 = x5 - x3 */                 \
+  MIRTJ_SDWA2("v_add_u32_sdwa", "%[x3]", "%[ay]", "%[bw]", SEL) /* s17 = x1 + x7 */                 \
+  MIRTJ_SDWA2("v_sub_u32_sdwa", "%[x1]", "%[ay]", "%[bw]", SEL) /* d17 = x1 - x7 */                 \
   "v_sub_u32 %[x7], %[x3], %[x6]\n\t"                                          /* s17 - s53 */                \
   "v_add_u32 %[t1], %[x5], %[x1]\n\t"                                          /* d53 + d17 */                \
   MIRTJ_MAD("%[x2]", "%[x2]", "%[k362]") MIRTJ_MAD("%[x7]", "%[x7]", "%[k362]") MIRTJ_MAD("%[t1]", "%[t1]", "%[k473]") \
@@ -182,18 +183,23 @@ __device__ __forceinline__ uint2 idct8_row_px(int x0, int x1, int x2, int x3, in
 #define MIRTJ_COL_OPERANDS                                                                                              \
   [t0] "=&v"(t0), [t1] "=&v"(t1), [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3), [x4] "=&v"(x4),       \
       [x5] "=&v"(x5), [x6] "=&v"(x6), [x7] "=&v"(x7)                                                                    \
-      : [qx] "v"(q.x), [qy] "v"(q.y), [qz] "v"(q.z), [qw] "v"(q.w), MIRTJ_K_OPERANDS
-template <bool kDc>
-__device__ __forceinline__ void idct8_col(const uint4& q, int (&y)[8], const IdctK& K) {
+      : [ax] "v"(a.x), [ay] "v"(a.y), [az] "v"(a.z), [aw] "v"(a.w), [bx] "v"(b.x), [by] "v"(b.y), [bz] "v"(b.z),      \
+        [bw] "v"(b.w), MIRTJ_K_OPERANDS
+template <bool kDc, bool kOdd>
+__device__ __forceinline__ void idct8_col(const uint4& a, const uint4& b, int (&y)[8], const IdctK& K) {
   int x0, x1, x2, x3, x4, x5, x6, x7, t0, t1;
-  if (kDc)
-    asm(MIRTJ_COL_HEAD
+  if (kDc)  // (column 0: even)
+    asm(MIRTJ_COL_HEAD("WORD_0")
         "v_add_u32 %[t0], 4, %[t0]\n\t"
         "v_add_u32 %[x0], 4, %[x0]\n\t"
         MIRTJ_IDCT_TAIL("%[x0]", "%[x1]", "%[x2]", "%[x3]", "%[x4]", "%[x5]", "%[x6]", "%[x7]", "%[t0]", "%[t1]")
         : MIRTJ_COL_OPERANDS);
+  else if (kOdd)
+    asm(MIRTJ_COL_HEAD("WORD_1")
+        MIRTJ_IDCT_TAIL("%[x0]", "%[x1]", "%[x2]", "%[x3]", "%[x4]", "%[x5]", "%[x6]", "%[x7]", "%[t0]", "%[t1]")
+        : MIRTJ_COL_OPERANDS);
   else
-    asm(MIRTJ_COL_HEAD
+    asm(MIRTJ_COL_HEAD("WORD_0")
         MIRTJ_IDCT_TAIL("%[x0]", "%[x1]", "%[x2]", "%[x3]", "%[x4]", "%[x5]", "%[x6]", "%[x7]", "%[t0]", "%[t1]")
         : MIRTJ_COL_OPERANDS);
   y[0] = x2; y[1] = x3; y[2] = x5; y[3] = t0; y[4] = x7; y[5] = x0; y[6] = x4; y[7] = x6;
@@ -239,28 +245,39 @@ __device__ __forceinline__ uint2 idct8_lo3_row_px(int x0, int x1, int x2, const 
   return make_uint2(o0, o1);
 }
 
-// column pass: qx = x0 | x1 << 16, qy = x2 | (x3 << 16, which is zero)
-template <bool kDc>
-__device__ __forceinline__ void idct8_lo3_col(uint32_t qx, uint32_t qy, int (&y)[8], const IdctK& K) {
+// column pass: q0, q1, q2 = rows 0, 1, 2 of a column pair; kOdd picks the column
+template <bool kDc, bool kOdd>
+__device__ __forceinline__ void idct8_lo3_col(uint32_t q0, uint32_t q1, uint32_t q2, int (&y)[8], const IdctK& K) {
   int x0, x1, x2, a, m, z, b, e0, e1, e2;
-#define MIRTJ_LO3_COL_HEAD                                                                                    \
-  "v_ashrrev_i32 %[x1], 16, %[qx]\n\t"                                                                        \
-  "v_bfe_i32 %[x0], %[qx], 0, 16\n\t"                                                                         \
-  "v_bfe_i32 %[x2], %[qy], 0, 16\n\t"                                                                         \
+#define MIRTJ_LO3_COL_HEAD_EVEN                                                                               \
+  "v_bfe_i32 %[x0], %[q0], 0, 16\n\t"                                                                         \
+  "v_bfe_i32 %[x1], %[q1], 0, 16\n\t"                                                                         \
+  "v_bfe_i32 %[x2], %[q2], 0, 16\n\t"                                                                         \
+  MIRTJ_LO3_COL_PRODUCTS
+#define MIRTJ_LO3_COL_HEAD_ODD                                                                                \
+  "v_ashrrev_i32 %[x0], 16, %[q0]\n\t"                                                                        \
+  "v_ashrrev_i32 %[x1], 16, %[q1]\n\t"                                                                        \
+  "v_ashrrev_i32 %[x2], 16, %[q2]\n\t"                                                                        \
+  MIRTJ_LO3_COL_PRODUCTS
+#define MIRTJ_LO3_COL_PRODUCTS                                                                                \
   MIRTJ_MAD("%[m]", "%[x1]", "%[k362]") MIRTJ_MAD("%[z]", "%[x1]", "%[k473]") MIRTJ_MAD("%[b]", "%[x1]", "%[k277]") \
   MIRTJ_MAD("%[a]", "%[x2]", "%[k362]")                                                                       \
   "s_nop " MIRTJ_STR(MIRTJ_NOP_LO3) "\n\t"
 #define MIRTJ_LO3_COL_OPERANDS                                                                                      \
   [a] "=&v"(a), [m] "=&v"(m), [z] "=&v"(z), [b] "=&v"(b), [e0] "=&v"(e0), [e1] "=&v"(e1), [e2] "=&v"(e2),           \
       [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2)                                                                \
-      : [qx] "v"(qx), [qy] "v"(qy), MIRTJ_K_OPERANDS
-  if (kDc)
-    asm(MIRTJ_LO3_COL_HEAD
+      : [q0] "v"(q0), [q1] "v"(q1), [q2] "v"(q2), MIRTJ_K_OPERANDS
+  if (kDc)  // (column 0: even)
+    asm(MIRTJ_LO3_COL_HEAD_EVEN
         "v_add_u32 %[x0], 4, %[x0]\n\t"
         MIRTJ_LO3_TAIL("%[x0]", "%[x1]", "%[x2]", "%[a]", "%[m]", "%[z]", "%[b]", "%[e0]", "%[e1]", "%[e2]")
         : MIRTJ_LO3_COL_OPERANDS);
+  else if (kOdd)
+    asm(MIRTJ_LO3_COL_HEAD_ODD
+        MIRTJ_LO3_TAIL("%[x0]", "%[x1]", "%[x2]", "%[a]", "%[m]", "%[z]", "%[b]", "%[e0]", "%[e1]", "%[e2]")
+        : MIRTJ_LO3_COL_OPERANDS);
   else
-    asm(MIRTJ_LO3_COL_HEAD
+    asm(MIRTJ_LO3_COL_HEAD_EVEN
         MIRTJ_LO3_TAIL("%[x0]", "%[x1]", "%[x2]", "%[a]", "%[m]", "%[z]", "%[b]", "%[e0]", "%[e1]", "%[e2]")
         : MIRTJ_LO3_COL_OPERANDS);
   y[0] = e0; y[1] = e1; y[2] = e2; y[3] = a; y[4] = b; y[5] = x1; y[6] = z; y[7] = x0;

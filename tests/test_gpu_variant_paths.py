@@ -64,3 +64,18 @@ def test_general_kernel_paths_match_the_oracle(tmp_path):
     env = dict(os.environ, MI_RTJ_LIB=lib, MI_RTJ_DEFER="1")  # the variant puts blocks off at the first DC-only block
     r = subprocess.run([sys.executable, "-c", CHILD, tests], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "variant ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("which", ["product", "general-paths"])
+def test_waves_that_take_all_three_parts_match_the_oracle(which):
+    """Large batches run k_decode with one wave per slot, taking the upper luma, lower luma and chroma blocks of each of
+    its groups in turn (span 3; the stream bytes then cross the fabric once).  MI_RTJ_ROTATE=1 asks for that
+    arrangement whatever the batch size: the same packets, mixed geometries and tables in one plan, the in-order
+    stream with unchanged blocks, arbitrary and truncated payloads."""
+    tests = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MI_RTJ_ROTATE="1")
+    if which != "product":
+        bld = __import__("importlib").import_module("gmerlin-avdecoder_amd.build")
+        env["MI_RTJ_LIB"] = bld.build_test_variant()
+    r = subprocess.run([sys.executable, "-c", CHILD, tests], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "variant ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -17,7 +17,7 @@ fsz = w * h * 3 // 2
 plan = dev.plan(np.tile(hdr0, (n, 1)), po, pl, np.arange(n, dtype=np.uint64) * np.uint64(fsz))
 d_out = dev.alloc(fsz * n)
 L = dev.L
-out = (C.c_ulonglong * 8)()
+out = (C.c_ulonglong * 16)()
 for _ in range(3):
     plan.decode(d_st, d_out)
 dev.sync()
@@ -27,9 +27,10 @@ for _ in range(4):
 dev.sync()
 L.mi_rtj_debug_stamps(out)
 v = list(out)
-waves = v[5]
-names = ["prologue", "classify+parse", "prefetch+lo test", "coords+transform+stores", "counted wait"]
-tot = sum(v[:5])
+waves = v[7]
+names = ["prologue", "classify+parse", "prefetch+lo test", "transform+stores", "counted wait", "coords+reads+range test", "-"]
+tot = sum(v[:7]) + sum(v[8:15])
 print(f"amp {amp}: waves {waves}, cycles per wave {tot / waves:.0f}")
-for nme, x in zip(names, v[:5]):
-    print(f"  {nme:26s} {x / waves:10.0f} cycles/wave  {100 * x / tot:5.1f} %")
+for base, what in ((0, "luma"), (8, "chroma")):
+    for nme, x in zip(names, v[base:base + 7]):
+        print(f"  {what:6s} {nme:26s} {x / waves:10.0f} cycles/wave  {100 * x / tot:5.1f} %")
