@@ -591,16 +591,6 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
   // clamp((int16(DC * q0) + 4) >> 3) 64 times over: every term of both passes but the DC path is zero
   // (lib/RTjpeg.c:2223-2238 is the reference's own shortcut for it).  The test reads the block's first 16 bytes.
   const bool dc_test = !kList && !rot && my_defer != nullptr && bt8 <= 14u;  // (the host never asks for both)
-  unsigned long long dcm_lo = 0, dcm_hi = 0, dcp_lo = 0, dcp_hi = 0;  // byte masks / expected bytes, wave-uniform
-  {
-    const uint32_t nb1 = bt8 + 2u;  // bytes 0 .. bt8+1 take part (byte 0, DC, is masked out again)
-    dcm_lo = nb1 >= 8u ? ~0ull : (1ull << (8u * nb1)) - 1ull;
-    dcm_hi = nb1 > 8u ? (nb1 >= 16u ? ~0ull : (1ull << (8u * (nb1 - 8u))) - 1ull) : 0ull;
-    dcm_lo &= ~0xFFull;
-    const unsigned long long run = 126ull - bt8;
-    if (bt8 + 1u < 8u) dcp_lo = run << (8u * (bt8 + 1u));
-    else dcp_hi = run << (8u * (bt8 + 1u - 8u));
-  }
   const int q_dc = chroma ? qt.ciqt[0] : qt.liqt[0];  // (dc_test: the part is fixed)
 
   // the dword that holds stream byte `p` and the four after it, bytes at or past data_len read as 0;
@@ -714,6 +704,18 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
     // are taken 64 at a time by k_decode_list, instead of a transform round here with most lanes idle ----
     bool dc_only = false, put_off = false;
     if (dc_test) {
+      // byte masks / expected bytes, wave-uniform (worked out here, on the path that uses them, so that they do not
+      // occupy eight scalar registers across the loop of every launch)
+      unsigned long long dcm_lo = 0, dcm_hi = 0, dcp_lo = 0, dcp_hi = 0;
+      {
+        const uint32_t nb1 = bt8 + 2u;  // bytes 0 .. bt8+1 take part (byte 0, DC, is masked out again)
+        dcm_lo = nb1 >= 8u ? ~0ull : (1ull << (8u * nb1)) - 1ull;
+        dcm_hi = nb1 > 8u ? (nb1 >= 16u ? ~0ull : (1ull << (8u * (nb1 - 8u))) - 1ull) : 0ull;
+        dcm_lo &= ~0xFFull;
+        const unsigned long long run = 126ull - bt8;
+        if (bt8 + 1u < 8u) dcp_lo = run << (8u * (bt8 + 1u));
+        else dcp_hi = run << (8u * (bt8 + 1u - 8u));
+      }
       const unsigned long long b_lo = (unsigned long long)__builtin_amdgcn_alignbyte(d2, d1, sh) << 32 |
                                       __builtin_amdgcn_alignbyte(d1, d0, sh);
       const unsigned long long b_hi = (unsigned long long)__builtin_amdgcn_alignbyte(d4, d3, sh) << 32 |
@@ -835,22 +837,31 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
     if (have_n) {
       inside_n = !kForceGenericPaths && __all(pos_n + kFetchSpan <= f.data_len);
       const Src s2 = source(it + 2u);
-      const uint32_t* offp = off + (s2.valid ? 6u * s2.mb + s2.kblk : 0u);
-      const uint8_t* g = data + pos_n;
-      const uint32_t* g4 = (const uint32_t*)(g - ((uintptr_t)g & 3u));
+      // addresses as a wave-uniform base (scalar registers) plus a 32-bit byte offset per lane: no 64-bit vector
+      // arithmetic (a packet is shorter than 2^32 bytes; the index of a packet has fewer than 2^30 entries)
+      const uint32_t offp = s2.valid ? 4u * (6u * s2.mb + s2.kblk) : 0u;
+      const uint8_t* g4b = data - ((uintptr_t)data & 3u);  // uniform
+      uint32_t g4o = (pos_n + (uint32_t)((uintptr_t)data & 3u)) & ~3u;
       // near the packet's end (rare) the bytes are fetched with masks, behind the wait at the end of this iteration —
       // fetched here they would occupy nine registers across the transform on every path; the hand-issued loads
       // below then read this packet's descriptor (64 valid bytes) instead
-      if (!inside_n) g4 = (const uint32_t*)(frames + blockIdx.y);
+      if (!inside_n) {
+        g4b = (const uint8_t*)(frames + blockIdx.y);
+        g4o = 0u;
+      }
       // one block, issued on every path that has a next group: its results take part in no selection before the
       // wait (a selection could be a register copy, and a copy of a register that is still being filled is wrong)
+      // (s_nop 4: a vector-memory instruction must not read a scalar register within five wait states of a vector
+      // instruction writing it — v_readlane_b32 reloading a spilled base, say — and the compiler, which pads such
+      // hazards in its own code, does not look inside an asm block.  The test build hit exactly that.)
       asm volatile(
-          "global_load_dwordx4 %0, %4, off\n\t"
-          "global_load_dwordx4 %1, %4, off offset:16\n\t"
-          "global_load_dword %2, %4, off offset:32\n\t"
-          "global_load_dword %3, %5, off"
+          "s_nop 4\n\t"
+          "global_load_dwordx4 %0, %4, %5\n\t"
+          "global_load_dwordx4 %1, %4, %5 offset:16\n\t"
+          "global_load_dword %2, %4, %5 offset:32\n\t"
+          "global_load_dword %3, %6, %7"
           : "=&v"(nb0), "=&v"(nb1), "=&v"(nb2), "=&v"(pos_nn)
-          : "v"(g4), "v"(offp)
+          : "v"(g4o), "s"(g4b), "v"(offp), "s"(off)
           : "memory");
     }
 
@@ -874,10 +885,8 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
 
     MIRTJ_STAMP(2);  // look-ahead loads issued, low-4x4 test
     if (live_any) {
-      uint32_t off32 = block_offset(grp, dmb, kblk, mb);
-      uint8_t* const plane = outbuf + plane_off;
-      uint32_t stride_v;
-      asm volatile("v_mov_b32 %0, %1" : "=v"(stride_v) : "s"(stride));  // kept in a vector register on purpose
+      const uint32_t off32 = block_offset(grp, dmb, kblk, mb);
+      uint8_t* plane = outbuf + plane_off;  // wave-uniform; steps from row to row on the scalar side
       auto put_packed = [&](uint2 o) {  // one row of the block, already clamped and packed
         // nontemporal (global_store_dwordx2 ... nt): the picture is not read again by this kernel, and the
         // stores are what a short chroma round waits for (-3.5 % on the kernel, v21_nontemporal_stores_ab.txt)
@@ -886,7 +895,7 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
         ov.x = o.x;
         ov.y = o.y;
         __builtin_nontemporal_store(ov, (u32x2_t*)(plane + off32));
-        off32 += stride_v;
+        plane += stride;
       };
       const IdctK K{362, 473, -669, 277, 128, 235};
       const IdctPK KP = idct_pk_constants();
@@ -915,7 +924,7 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
 #pragma unroll
           for (int r = 0; r < 8; r++) {
             __builtin_nontemporal_store(ov, (u32x2_t*)(plane + off32));
-            off32 += stride_v;
+            plane += stride;
           }
         }
       } else if (lo) {

@@ -59,12 +59,15 @@ def test_hand_issued_loads_of_k_decode_are_not_touched_before_their_wait(tmp_pat
     import subprocess
     import sys
     csrc = os.path.join(ROOT, "gmerlin-avdecoder_amd", "csrc")
-    out = tmp_path / "lib.so"
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                    "-Wno-unused-function", "-save-temps=obj", "-o", str(out), os.path.join(csrc, "mi_rtjpeg.hip")],
-                   check=True, capture_output=True, cwd=str(tmp_path))
-    asm = tmp_path / "mi_rtjpeg-hip-amdgcn-amd-amdhsa-gfx950.s"
-    assert asm.exists()
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_async_loads.py"), str(asm)],
-                       capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout + r.stderr
+    # the shipped build and the test build of tests/test_gpu_variant_paths.py (its own flags, its own register allocation)
+    for name, flags in (("product", []), ("general", ["-DMIRTJ_TEST_GENERIC_PATHS", "-DMIRTJ_DC_DEFER=1"])):
+        d = tmp_path / name
+        d.mkdir()
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                        "-Wno-unused-function", "-save-temps=obj", *flags, "-o", str(d / "lib.so"),
+                        os.path.join(csrc, "mi_rtjpeg.hip")], check=True, capture_output=True, cwd=str(d))
+        asm = d / "mi_rtjpeg-hip-amdgcn-amd-amdhsa-gfx950.s"
+        assert asm.exists()
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_async_loads.py"), str(asm)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, name + ": " + r.stdout + r.stderr

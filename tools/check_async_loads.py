@@ -47,6 +47,12 @@ def check(path, kernel="k_decode", fills=4, singles=1):
     if len(blocks) != 1:
         return [f"{kernel}: expected one hand-issued load block, found {len(blocks)}"]
     b0, b1 = blocks[0]
+    # the loads take their bases from scalar registers: a vector instruction just in front of the block may have
+    # written one (v_readlane_b32 reloading a spilled value), and nobody pads that hazard inside an asm block
+    first = next(t.strip() for t in body[b0 + 1:b1] if t.strip())
+    if first != "s_nop 4":
+        return [f"{kernel}: the hand-issued load block must open with 's_nop 4' (scalar base written by a vector "
+                f"instruction, read by a vector-memory instruction: five wait states), found '{first}'"]
     pending = set()
     for t in body[b0:b1]:
         t = t.strip()
