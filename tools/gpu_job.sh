@@ -1,5 +1,3 @@
 set -u
-mkdir -p gpurun_out/r02e
-timeout -k 10 500 python bench.py > gpurun_out/r02e/bench.json 2> gpurun_out/r02e/bench.err; echo "bench rc=$?"
-python -c "
-import json; d=json.load(open('gpurun_out/r02e/bench.json')); print(d['value'], d['roofline'], d.get('roofline_valu',{}).get('frac_of_expensive_rate'), d['parity_checked'], d['parity_mismatches'], d['end_to_end']['fps'])"
+mkdir -p gpurun_out/r02f
+bash tools/ab_libs.sh 2 --no-stress --no-e2e -- product lib_ldspad900.so lib_ldspad2600.so 2>&1 | tee gpurun_out/r02f/ab_occupancy.txt
