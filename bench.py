@@ -176,8 +176,27 @@ def kernel_source_digest():
     csrc = os.path.join(ROOT, "gmerlin-avdecoder_amd", "csrc")
     for name in sorted(os.listdir(csrc)):
         if name.endswith((".h", ".hip", ".cpp")) and ("kernels" in name or "idct" in name or name == "rtj_common.h"):
-            hsh.update(open(os.path.join(csrc, name), "rb").read())
+            hsh.update(name.encode())
+            hsh.update(strip_comments(open(os.path.join(csrc, name), encoding="utf-8").read()).encode())
     return hsh.hexdigest()[:16]
+
+
+def strip_comments(text):
+    """The code of a source file without // comments, trailing blanks and empty lines: what the digest covers (a
+    reworded comment does not make a profile stale)."""
+    out = []
+    for line in text.split("\n"):
+        cut = len(line)
+        k = line.find("//")
+        while k >= 0:
+            if line[:k].count('"') % 2 == 0:  # not inside a string literal
+                cut = k
+                break
+            k = line.find("//", k + 2)
+        line = line[:cut].rstrip()
+        if line:
+            out.append(line)
+    return "\n".join(out)
 
 
 def pmc_profile():

@@ -397,16 +397,18 @@ constexpr bool kForceGenericPaths = true;
 #else
 constexpr bool kForceGenericPaths = false;
 #endif
-// waves per part of a picture with `groups` macroblock groups: enough for kDecIters groups per wave and, for
-// small batches, enough that `frames` pictures still make kDecMinWaves waves (one packet: a wave per group; a
-// wave then works through fewer groups than kDecIters).  Which XCD the three parts of a group run on matters
-// more than their number.  With part-major block numbering, measured at 1080p x 4096 (tools/ab_slots.sh,
+// waves per part (span 1) or per frame (span 3: a wave takes all three parts of its groups) of a picture with `groups`
+// macroblock groups: enough for kDecIters groups per wave and, for small batches, enough that `frames` pictures
+// still make kDecMinWaves waves (one packet: a wave per group and part; a wave then works through fewer groups than
+// kDecIters).  With a wave per part, which XCD the three parts of a group run on matters more than their number.  With part-major block numbering, measured at 1080p x 4096 (tools/ab_slots.sh,
 // profiles/r01/v19_waves_per_part_ab.txt): 25..45 odd 5.17-5.30 ms, 24 / 40 / 48 / 56 5.42-5.72, 32 and 64
 // 5.73-5.98 — with a multiple of 8 the three parts of a group share an XCD (workgroups are dealt round-robin to
 // the 8 XCDs) and their stream bytes and block offsets come from HBM once, and that is the SLOW arrangement;
 // spreading the parts over XCDs reads them three times (HBM traffic 1.17x -> 1.5x the algorithmic bytes) and is
 // 5 % faster all the same.  k_decode therefore numbers its blocks slot-major (5.23-5.25 ms whatever the count,
-// v19_block_numbering_ab.txt); the count is kept odd for good measure.
+// v19_block_numbering_ab.txt); the count is kept odd for good measure.  With a wave per frame slot (span 3) nothing
+// is read twice, and 32 / 64 / 128 waves per frame are still 9 % slower than 24, 25, 43 or 51
+// (profiles/r02/ab_waves_per_frame_rotate.txt; cause not established): the count stays odd.
 constexpr uint32_t kDecMinWaves = 65536;
 __host__ __device__ constexpr uint32_t decode_slots(uint32_t groups, uint32_t frames, uint32_t span = 1u) {
   const uint32_t by_iters = (groups + (uint32_t)kDecIters - 1u) / (uint32_t)kDecIters;
@@ -419,15 +421,19 @@ constexpr uint32_t kDecRotateMinGroups = 65536;  // groups in a batch from which
 constexpr uint32_t kFetchSpan = 72;             // a block's loads stay below its start + this (64 + alignment + look-ahead)
 
 // ---------------------------------------------------------------------------------------
-// k_decode: grid (3 * slots, frames), one wave per workgroup; slots = decode_slots().  A group is
-// kMbPerGroup consecutive macroblocks; a wave owns one PART of up to kDecIters groups (slot, slot + slots, ...):
+// k_decode: one wave per workgroup; slots = decode_slots().  A group is kMbPerGroup consecutive macroblocks and
+// has three PARTS of 64 blocks:
 //   part 0: the 64 upper luma blocks (Y0,Y1 of each MB), part 1: the 64 lower ones,
 //   part 2: 32 Cb + 32 Cr blocks.
+// span 3 (batches): grid (slots, frames); a wave takes the three parts of each of its up to kDecIters groups
+// (slot, slot + slots, ...) in turn.  span 1 (small batches, one packet): grid (3 * slots, frames); a wave owns one
+// part of its groups.
 // Lanes of a wave hold horizontally adjacent blocks, so every row store of a wave covers 512
 // (luma) or 2x256 (chroma) contiguous bytes.  Each lane pulls its own block's bytes from the
 // stream (neighbouring lanes read neighbouring bytes, so the wave's loads stay within a few
-// cache lines), parses them into a private LDS scratch (transposed, so a column is one 16-byte
-// read), then runs both transform passes entirely in registers.
+// cache lines), parses them into a private LDS scratch (by column pairs, coef_byte() below: two 16-byte
+// reads are a column pair, one row to a dword), then runs both transform passes entirely in registers —
+// two values to a register where the block's values allow it (rtj_idct_pk.h).
 //
 // The kernel is bound by vector-instruction issue, so the parse loop is built to cost few
 // instructions per stream byte:
