@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=["frames1080", "streams4k", "mixed"], default="frames1080")
-    ap.add_argument("--frames", type=int, default=None, help="frames resident per GPU (frames1080: 4096) / per stream")
+    ap.add_argument("--frames", type=int, default=None, help="frames resident per GPU (frames1080: 8192) / per stream")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1088)
     ap.add_argument("--quality", type=int, default=255)
@@ -306,7 +306,10 @@ def main():
         return
 
     w, h, Q = a.width, a.height, a.quality
-    n = a.frames or 4096
+    # 8192 pictures per launch (31 GB of packets and planes): the launch is long enough that the last, partly filled
+    # round of resident waves of each kernel no longer shows (profiles/r02/ab_frames_per_launch.txt: 4096 -> 8192 -> 16384
+    # pictures per launch = 6.64 -> 6.32 -> 6.24 ms per 4096 pictures)
+    n = a.frames or 8192
     r = run_frames(a, dev, rank, n, a.amp, a.steps, a.warmup, barrier, sync_all)
     plan, info, fsz = r["plan"], r["info"], r["fsz"]
 
