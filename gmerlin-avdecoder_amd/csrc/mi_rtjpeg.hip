@@ -874,6 +874,13 @@ int decode_one_launch(mi_rtj_ctx* c, const uint8_t* pkt, size_t len) {
     c->single->n = 1;
     c->single->defer_on = false;  // one packet: a second launch costs more than idle lanes
     c->single->h_frames.resize(1);
+    // the A/B switches of the index are read once per decoder, not once per packet
+    const char* mode = getenv("MI_RTJ_INDEX");
+    c->single->serial_index = mode && strcmp(mode, "serial") == 0;
+    const char* em = getenv("MI_RTJ_EMIT");
+    c->single->emit_walk = em && strcmp(em, "walk") == 0;
+    const char* sp = getenv("MI_RTJ_SPEC");
+    c->single->spec_mode = sp ? atoi(sp) : -1;
   }
   mi_rtj_plan* p = c->single;
   const int rc = fill_frame(c, pkt, 0, (uint32_t)len, 0, 0, &p->h_frames[0]);
@@ -913,13 +920,7 @@ int decode_one_launch(mi_rtj_ctx* c, const uint8_t* pkt, size_t len) {
   p->n_blocks = (uint64_t)f.nmb * 6;
   p->max_groups = (f.nmb + kMbPerGroup - 1) / kMbPerGroup;
   {
-    const char* mode = getenv("MI_RTJ_INDEX");
-    p->serial_index = mode && strcmp(mode, "serial") == 0;
-    const char* em = getenv("MI_RTJ_EMIT");
-    p->emit_walk = em && strcmp(em, "walk") == 0;
-    const char* sp = getenv("MI_RTJ_SPEC");
-    p->spec_mode = sp ? atoi(sp) : -1;
-    const int rc2 = plan_alloc_chunks(p);
+    const int rc2 = plan_alloc_chunks(p);  // lays the packet's chunks out; allocates only when it is larger than any before it
     if (rc2 != MI_RTJ_OK) return rc2;
   }
   // pageable source: the runtime stages it; a private pinned staging copy measured no faster
