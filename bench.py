@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", choices=["frames1080", "streams4k", "mixed"], default="frames1080")
-    ap.add_argument("--frames", type=int, default=None, help="frames resident per GPU (frames1080: 8192) / per stream")
+    ap.add_argument("--frames", type=int, default=None, help="frames resident per GPU (frames1080: 16384) / per stream")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1088)
     ap.add_argument("--quality", type=int, default=255)
@@ -306,10 +306,11 @@ def main():
         return
 
     w, h, Q = a.width, a.height, a.quality
-    # 8192 pictures per launch (31 GB of packets and planes): the launch is long enough that the last, partly filled
-    # round of resident waves of each kernel no longer shows (profiles/r02/ab_frames_per_launch.txt: 4096 -> 8192 -> 16384
-    # pictures per launch = 6.64 -> 6.32 -> 6.24 ms per 4096 pictures)
-    n = a.frames or 8192
+    # 16384 pictures per launch (61 GB of packets and planes, ~110 GB with the index buffers): the launch is long enough
+    # that the last, partly filled round of resident waves of each kernel no longer shows
+    # (profiles/r02/ab_frames_per_launch.txt: 4096 -> 8192 -> 16384 pictures per launch = 6.64 -> 6.32 -> 6.24 ms per 4096
+    # pictures; with the walkers' records interleaved per wave 6.05-6.10 at 16384, ab_walker_record_layout.txt)
+    n = a.frames or 16384
     r = run_frames(a, dev, rank, n, a.amp, a.steps, a.warmup, barrier, sync_all)
     plan, info, fsz = r["plan"], r["info"], r["fsz"]
 

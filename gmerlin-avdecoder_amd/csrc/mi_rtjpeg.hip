@@ -290,7 +290,7 @@ int plan_alloc_chunks(mi_rtj_plan* p) {
         p->cap_spec = 0;  // a failed hipMalloc below must not leave freed pointers behind
       }
       HIPCHK(c, hipMalloc((void**)&p->d_spec_chunks, sizeof(SpecChunkDev) * p->n_spec));
-      HIPCHK(c, hipMalloc((void**)&p->d_spec_rec, sizeof(uint16_t) * kSpecCap * (p->n_spec + 1)));  // + a spare row for idle lanes
+      HIPCHK(c, hipMalloc((void**)&p->d_spec_rec, sizeof(uint16_t) * kSpecCap * ((p->n_spec + 1 + 63) / 64 * 64)));  // whole waves of walkers, + a spare walker for idle lanes
       HIPCHK(c, hipMalloc((void**)&p->d_spec_nrec, sizeof(uint32_t) * p->n_spec));
       HIPCHK(c, hipMalloc((void**)&p->d_spec_wstart, sizeof(uint32_t) * p->n_spec));
       HIPCHK(c, hipMalloc((void**)&p->d_spec_hand, sizeof(uint2) * p->n_spec));

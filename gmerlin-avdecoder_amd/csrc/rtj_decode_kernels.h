@@ -135,7 +135,12 @@ __device__ __forceinline__ void walk_blocks(const FrameDev& f, const uint8_t* __
 __device__ __forceinline__ uint32_t walk_record(const FrameDev& f, const uint8_t* __restrict__ stream,
                                                 const QTab* __restrict__ lut, uint32_t p_start, uint32_t mid,
                                                 uint32_t limit, uint16_t* __restrict__ out, uint32_t cap,
-                                                uint32_t& take, uint32_t& tail) {
+                                                uint32_t& take, uint32_t& tail, uint32_t walker = 0,
+                                                bool interleaved = false) {
+  // where record i of `walker` lives relative to `out` (see spec_rec_index, rtj_spec_kernels.h); plain rows otherwise
+  auto at = [&](uint32_t i) -> size_t {
+    return interleaved ? ((size_t)(i >> 3) * 64u + (walker & 63u)) * 8u + (i & 7u) : (size_t)i;
+  };
   const int lane = threadIdx.x & 63;
   const uint8_t* g = stream + f.data_off;
   const uint32_t len = f.data_len;
@@ -171,7 +176,7 @@ __device__ __forceinline__ uint32_t walk_record(const FrameDev& f, const uint8_t
     acc = (uint32_t)lane == (k & 63u) ? p - p_start : acc;
     if ((k & 63u) == 63u) {
       const uint32_t idx = (k & ~63u) + (uint32_t)lane;
-      if (idx < cap) out[idx] = (uint16_t)acc;
+      if (idx < cap) out[at(idx)] = (uint16_t)acc;
     }
     k++;
     const uint32_t lp = p - base;
@@ -199,7 +204,7 @@ __device__ __forceinline__ uint32_t walk_record(const FrameDev& f, const uint8_t
   }
   if (k & 63u) {  // the last, partial group of records
     const uint32_t idx = (k & ~63u) + (uint32_t)lane;
-    if (idx < k && idx < cap) out[idx] = (uint16_t)acc;
+    if (idx < k && idx < cap) out[at(idx)] = (uint16_t)acc;
   }
   return k;
 }

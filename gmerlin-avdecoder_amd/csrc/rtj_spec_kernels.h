@@ -50,6 +50,21 @@ constexpr int kSpecSpan = kSpecLeadLong + kSpecChunk;  // the longest span a wal
 constexpr int kSpecTile = 128;    // bytes per lane fetched at a time (one cache line)
 constexpr int kSpecCap = 2048;    // block starts a walker can record (16-bit, relative to its first byte):
                                   // enough for blocks of 1.75 bytes on average over its span
+// Where a walker's records live.  MIRTJ_SPEC_REC_INTERLEAVE == 0: a row of kSpecCap records per walker (4 KB, of which
+// a tenth is used: the 64 lanes of a wave store 16 bytes each into 64 rows 4 KB apart).  == 1: the 64 walkers of a
+// wave share one region of 64 * kSpecCap records, laid out [group of 8 records][lane][8]: what a wave stores at a time
+// is contiguous, and the region fills from its start.
+#ifndef MIRTJ_SPEC_REC_INTERLEAVE
+#define MIRTJ_SPEC_REC_INTERLEAVE 1
+#endif
+constexpr bool kSpecRecInterleave = MIRTJ_SPEC_REC_INTERLEAVE != 0;
+__host__ __device__ constexpr size_t spec_rec_base(uint32_t walker) {  // in records, from the start of the buffer
+  return kSpecRecInterleave ? (size_t)(walker >> 6) * (64u * (size_t)kSpecCap) : (size_t)walker * (size_t)kSpecCap;
+}
+__host__ __device__ constexpr size_t spec_rec_index(uint32_t walker, uint32_t i) {
+  return spec_rec_base(walker) +
+         (kSpecRecInterleave ? ((size_t)(i >> 3) * 64u + (walker & 63u)) * 8u + (i & 7u) : (size_t)i);
+}
 constexpr uint64_t kSpecMinWalkers = 40000;  // below this (~100 MB of packets) the exact kernels index a batch faster:
                                             // a walker is one lane and runs ~0.35 ms whatever the batch (host policy)
 constexpr int kSpecRingRow = 64 + 16;       // LDS bytes per lane of the record ring: 32 records + bank padding
@@ -194,7 +209,7 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
   // ring per lane in LDS and leave for HBM eight at a time (one 16-byte store): a 2-byte global store
   // per block end was 40 % of the kernel.  Idle lanes of the last wave own the spare row after the last
   // walker's.
-  const size_t row0 = 2u * (size_t)(act ? g : total) * (size_t)kSpecCap;
+  const uint32_t gw = act ? g : total;  // idle lanes of the last wave own the spare walker after the last one
   uint8_t* const rec8 = (uint8_t*)records;
   uint8_t* const ring = s_ring + lane * kSpecRingRow;
   const uint32_t ring_a = lds_address(ring);
@@ -207,7 +222,7 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
     while (__any((int)(cnt - flushed) >= least)) {
       if ((int)(cnt - flushed) >= least) {
         const uint4 v = *(const uint4*)(ring + ((flushed & 31u) << 1));  // flushed is a multiple of 8
-        if (flushed <= (uint32_t)kSpecCap - 8u) *(uint4*)(rec8 + row0 + 2u * flushed) = v;
+        if (flushed <= (uint32_t)kSpecCap - 8u) *(uint4*)(rec8 + 2u * spec_rec_index(gw, flushed)) = v;
         flushed += 8u;
       }
     }
@@ -372,8 +387,8 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
     // kSpecVerBatch chunks at a time so that it waits for memory once per batch, not once per chunk.
     constexpr uint32_t kWaves = kSpecVerThreads / 64;
     for (uint32_t j0 = (uint32_t)wv; j0 < tile_n; j0 += kSpecVerBatch * kWaves) {
-      uint32_t base[kSpecVerBatch], m[kSpecVerBatch], start[kSpecVerBatch], mmax = 0;
-      const uint16_t* R[kSpecVerBatch];
+      uint32_t base[kSpecVerBatch], m[kSpecVerBatch], start[kSpecVerBatch], first[kSpecVerBatch], mmax = 0;
+      uint32_t R[kSpecVerBatch];  // the walker whose records are copied
 #pragma unroll
       for (int u = 0; u < kSpecVerBatch; u++) {
         const uint32_t j = min(j0 + (uint32_t)u * kWaves, tile_n - 1u);
@@ -381,7 +396,8 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
         base[u] = s_base[j];
         m[u] = have && base[u] <= last ? min(s_cnt[j], last + 1u - base[u]) : 0u;  // clipped to the packet's own index
         start[u] = wstart[sc0 + c0 + j];
-        R[u] = records + (size_t)(sc0 + c0 + j) * kSpecCap + s_i0[j];
+        R[u] = sc0 + c0 + j;
+        first[u] = s_i0[j];
         mmax = max(mmax, m[u]);
       }
       for (uint32_t k0 = 0; k0 < mmax; k0 += 256) {
@@ -391,7 +407,7 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
 #pragma unroll
           for (int t = 0; t < 4; t++) {
             const uint32_t k = k0 + 64u * (uint32_t)t + (uint32_t)lane;
-            v[u][t] = k < m[u] ? R[u][k] : 0u;
+            v[u][t] = k < m[u] ? records[spec_rec_index(R[u], first[u] + k)] : 0u;
           }
         }
 #pragma unroll
@@ -434,7 +450,7 @@ __global__ __launch_bounds__(64) void k_spec_repair(const FrameDev* __restrict__
     const uint32_t limit = (sc.c + 1u) * (uint32_t)kSpecChunk;  // where the walker's span ends
     uint32_t take, tail;
     const uint32_t cnt = walk_record(f, stream, lut, e.y, sc.c * (uint32_t)kSpecChunk, limit,
-                                     records + (size_t)e.x * kSpecCap, (uint32_t)kSpecCap, take, tail);
+                                     records + spec_rec_base(e.x), (uint32_t)kSpecCap, take, tail, e.x, kSpecRecInterleave);
     if (threadIdx.x == 0) {
       nrec[e.x] = cnt;
       wstart[e.x] = e.y;
