@@ -366,7 +366,6 @@ def main():
             "speculative_index": dict(zip(("packets_proven", "stream_chunks"), plan.spec_stats()),
                                       chunks_repaired=getattr(plan, "repaired", 0),
                                       walker_lead_bytes=plan.spec_lead()[0]),  # what the policy chose for the next launch
-            "blocks_put_off": plan.deferred(),
             "path_gbs": round(alg_bytes * a.steps / dt / 1e9, 2),
         }
         # the vector-issue roof of k_decode: instructions per launch from the PMC profile of these sources

@@ -29,7 +29,7 @@ EXPORTS = ["mi_rtj_device_count", "mi_rtj_create", "mi_rtj_destroy", "mi_rtj_las
            "mi_rtj_plan_decode", "mi_rtj_plan_info", "mi_rtj_plan_profile", "mi_rtj_plan_times",
            "mi_rtj_plan_read_index", "mi_rtj_synth_frames", "mi_rtj_encode_bound", "mi_rtj_encode_frames",
            "mi_rtj_get_tables", "mi_rtj_yuv420_to_rgb", "mi_rtj_encode_stream", "mi_rtj_decode_nocopy",
-           "mi_rtj_copy_ceiling", "mi_rtj_plan_spec_stats", "mi_rtj_plan_spec_lead", "mi_rtj_plan_deferred",
+           "mi_rtj_copy_ceiling", "mi_rtj_plan_spec_stats", "mi_rtj_plan_spec_lead",
            "mi_rtj_plan_step_times", "mi_rtj_pipe_create", "mi_rtj_pipe_destroy", "mi_rtj_pipe_room",
            "mi_rtj_pipe_pending", "mi_rtj_pipe_submit", "mi_rtj_pipe_next", "mi_rtj_pipe_peek_tag", "mi_rtj_pipe_flush"]
 
@@ -71,7 +71,6 @@ def load():
     L.mi_rtj_plan_times.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.mi_rtj_plan_spec_stats.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.mi_rtj_plan_spec_lead.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
-    L.mi_rtj_plan_deferred.argtypes = [vp, C.POINTER(C.c_longlong)]
     L.mi_rtj_plan_step_times.argtypes = [vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
     L.mi_rtj_pipe_create.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.mi_rtj_pipe_create.restype = vp
@@ -152,12 +151,6 @@ class Plan:
         n = C.c_int()
         self.owner._chk(self.owner.L.mi_rtj_plan_step_times(self.h, ms, max_steps, C.byref(n)))
         return [float(ms[i]) for i in range(min(n.value, max_steps))]
-
-    def deferred(self):
-        """8x8 blocks the last decode left to k_decode_list (0: the plan puts nothing off)."""
-        n = C.c_longlong()
-        self.owner._chk(self.owner.L.mi_rtj_plan_deferred(self.h, C.byref(n)))
-        return n.value
 
     def spec_lead(self):
         """(bytes a walker parses before its chunk in the next decode, decodes left without speculation)."""

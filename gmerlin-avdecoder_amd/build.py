@@ -4,8 +4,10 @@
 
 hipcc cross-compiles without a GPU.  The .so is git-ignored but travels to the GPU box."""
 import os
+import shutil
 import subprocess
 import sys
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -34,13 +36,31 @@ def build(force=False, verbose=False, out=None):
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     extra = os.environ.get("MI_RTJ_CFLAGS", "").split()
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function"] + extra + ["-o", out or LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    # compiled in a scratch directory with the device assembly kept: EVERY library built here (the product, the test
+    # variant, A/B builds with other MI_RTJ_CFLAGS) has its k_decode checked for the one thing the compiler does not
+    # know — the hand-issued look-ahead loads and their counted wait (tools/check_async_loads.py) — and a finding
+    # fails the build
+    tmp = tempfile.mkdtemp(prefix="mirtj_build_")
+    try:
+        so = os.path.join(tmp, "lib.so")
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
+               "-Wno-unused-function", "-save-temps=obj"] + extra + ["-o", so] + [os.path.join(CSRC, s) for s in SOURCES]
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=tmp)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+        asm = os.path.join(tmp, "mi_rtjpeg-hip-amdgcn-amd-amdhsa-gfx950.s")
+        chk = os.path.join(HERE, "..", "tools", "check_async_loads.py")
+        # (MI_RTJ_SKIP_ASYNC_CHECK=1: timing experiments only — the checker reads the text in layout order and takes a
+        # block the compiler merely PLACED behind the load block for one that runs behind it)
+        if os.path.exists(chk) and not os.environ.get("MI_RTJ_SKIP_ASYNC_CHECK"):
+            c = subprocess.run([sys.executable, chk, asm], capture_output=True, text=True)
+            if c.returncode != 0:
+                raise RuntimeError("k_decode's hand-issued loads are not safe in this build:\n" + c.stdout + c.stderr)
+        shutil.move(so, out or LIB)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
     return out or LIB
 
 
@@ -50,12 +70,12 @@ TEST_VARIANT = os.path.join(LIBDIR, "libmi_rtjpeg_generic_paths.so")
 def build_test_variant(force=False):
     """The same library compiled with -DMIRTJ_TEST_GENERIC_PATHS: the kernels always take the paths
     that real tables and whole packets rarely reach (run-time raw-byte count in the parse loop, masked
-    loads near a packet's end; a single DC-only block is enough for a group to put its other blocks off).  Loaded only by tests/test_gpu_variant_paths.py."""
+    loads near a packet's end).  Loaded only by tests/test_gpu_variant_paths.py."""
     if not force and os.path.exists(TEST_VARIANT) and \
             all(os.path.getmtime(f) <= os.path.getmtime(TEST_VARIANT) for f in _deps()):
         return TEST_VARIANT
     old = os.environ.get("MI_RTJ_CFLAGS")
-    os.environ["MI_RTJ_CFLAGS"] = ((old + " ") if old else "") + "-DMIRTJ_TEST_GENERIC_PATHS -DMIRTJ_DC_DEFER=1"
+    os.environ["MI_RTJ_CFLAGS"] = ((old + " ") if old else "") + "-DMIRTJ_TEST_GENERIC_PATHS"
     try:
         return build(force=True, out=TEST_VARIANT)
     finally:

@@ -28,7 +28,6 @@ using namespace mirtj;
 namespace {
 
 constexpr size_t kAllocPad = 256;  // kernels may read a few bytes past a packet's last dword
-constexpr uint64_t kDeferMinGroups = 4096;  // plans with fewer macroblock groups never put blocks off
 constexpr int kMaxPlanFrames = 65535;       // a plan's frames are the y dimension of every grid
 
 std::mutex g_err_mu;
@@ -95,9 +94,6 @@ struct mi_rtj_plan {
   uint32_t* d_spec_todo = nullptr;         // [n + 1]: count, then the packets left to the exact kernels
   int cap_spec_frames = 0;
   uint32_t* d_spec_state = nullptr;        // [2]: launches in a row that refused every packet, launches left paused
-  unsigned long long* d_defer = nullptr;   // [k_decode waves][kDecIters]: lanes whose blocks k_decode put off
-  size_t cap_defer = 0, defer_words = 0;   // allocated / used by the last launch
-  bool defer_on = true;                    // MI_RTJ_DEFER=0 switches the putting-off off (A/B)
   int rotate = -1;                         // MI_RTJ_ROTATE: 1 / 0 = a k_decode wave takes all three parts of its groups / one part; -1 = by batch size
   const uint8_t* prev_pic = nullptr;       // sessions: where unchanged blocks of this launch are copied from
   std::vector<Timed> ev[MI_RTJ_NUM_KERNELS];  // one pair per launch while profiling
@@ -444,36 +440,32 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
   // the A/B override is honoured only where it still covers every group
   // a wave per (slot, part) or, in batches that still make enough waves that way, per slot: the wave then takes the
   // three parts of each of its groups in turn and the group's stream bytes cross the fabric once (kernel header)
-  const uint32_t span = p->defer_on ? 1u
-                        : p->rotate >= 0 ? (p->rotate ? 3u : 1u)
+  const uint32_t span = p->rotate >= 0 ? (p->rotate ? 3u : 1u)
                         : (uint64_t)p->n * p->max_groups >= (uint64_t)kDecRotateMinGroups ? 3u : 1u;
   const uint32_t dslots = p->dec_slots && p->dec_slots * (uint32_t)kDecIters >= p->max_groups
                               ? p->dec_slots
                               : decode_slots(p->max_groups, (uint32_t)p->n, span);
-  // groups with many DC-only blocks fill those in and put their other blocks off (one lane mask per wave and
-  // iteration, zeroed here); k_decode_list takes the blocks put off, 64 per round.  MI_RTJ_DEFER=0: never put off.
-  unsigned long long* defer = nullptr;
-  if (p->defer_on) {
-    const size_t words = (size_t)dslots * 3u * (size_t)p->n * (size_t)kDecIters;
-    if (words > p->cap_defer) {
-      if (p->d_defer) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(p->d_defer);
-        p->d_defer = nullptr;
-        p->cap_defer = 0;
-      }
-      HIPCHK(c, hipMalloc((void**)&p->d_defer, words * sizeof(unsigned long long)));
-      p->cap_defer = words;
+  {
+    const dim3 grid(span == 3u ? dslots : dslots * 3u, p->n), block(kDecThreads);
+    uint8_t* const out8 = (uint8_t*)d_out;
+    // four instantiations: (a wave takes all three parts of its groups | one part) x (unchanged blocks stay | are
+    // fetched from the previous packet's picture); a launch runs the one that carries nothing else
+    if (span == 3u) {
+      if (p->prev_pic)
+        hipLaunchKernelGGL((k_decode<true, true>), grid, block, 0, c->stream, p->d_frames, st, c->d_lut, p->d_blkoff, out8,
+                           p->prev_pic);
+      else
+        hipLaunchKernelGGL((k_decode<true, false>), grid, block, 0, c->stream, p->d_frames, st, c->d_lut, p->d_blkoff, out8,
+                           (const uint8_t*)nullptr);
+    } else {
+      if (p->prev_pic)
+        hipLaunchKernelGGL((k_decode<false, true>), grid, block, 0, c->stream, p->d_frames, st, c->d_lut, p->d_blkoff, out8,
+                           p->prev_pic);
+      else
+        hipLaunchKernelGGL((k_decode<false, false>), grid, block, 0, c->stream, p->d_frames, st, c->d_lut, p->d_blkoff,
+                           out8, (const uint8_t*)nullptr);
     }
-    defer = p->d_defer;
-    p->defer_words = words;
-    HIPCHK(c, hipMemsetAsync(defer, 0, words * sizeof(unsigned long long), c->stream));
   }
-  hipLaunchKernelGGL(k_decode, dim3(span == 3u ? dslots : dslots * 3u, p->n), dim3(kDecThreads), 0, c->stream, p->d_frames,
-                     st, c->d_lut, p->d_blkoff, (uint8_t*)d_out, defer, p->prev_pic, span);
-  if (defer)
-    hipLaunchKernelGGL(k_decode_list, dim3(dslots * 3u, p->n), dim3(kDecThreads), 0, c->stream, p->d_frames, st, c->d_lut,
-                       p->d_blkoff, (uint8_t*)d_out, defer);
   if ((rc = end(MI_RTJ_K_DECODE)) != MI_RTJ_OK) return rc;
   HIPCHK(c, hipGetLastError());
   p->launches++;
@@ -671,11 +663,6 @@ mi_rtj_plan* mi_rtj_plan_create(mi_rtj_ctx* c, int n, const uint8_t* headers, co
     p->spec_mode = sp ? atoi(sp) : -1;
     const char* ds = getenv("MI_RTJ_DEC_SLOTS");
     p->dec_slots = ds ? (uint32_t)atoi(ds) : 0u;
-    // putting blocks off costs a memset and a second launch: batches only (the one-packet plan never does)
-    const char* df = getenv("MI_RTJ_DEFER");
-    // (off unless asked for: rows with gaps, and the 8-byte row pieces of k_decode_list, cost more in HBM read-modify-
-    // write cycles than the idle lanes they save — DESIGN.md; MI_RTJ_DEFER=1 switches it on for plans of kDeferMinGroups)
-    p->defer_on = df ? atoi(df) != 0 && (atoi(df) > 1 || (uint64_t)p->n * p->max_groups >= kDeferMinGroups || true) : false;
     const char* ro = getenv("MI_RTJ_ROTATE");
     p->rotate = ro ? (atoi(ro) != 0) : -1;
   }
@@ -718,7 +705,6 @@ void mi_rtj_plan_destroy(mi_rtj_plan* p) {
   if (p->d_spec_todo) (void)hipFree(p->d_spec_todo);
   if (p->d_spec_state) (void)hipFree(p->d_spec_state);
   if (p->d_spec_ok) (void)hipFree(p->d_spec_ok);
-  if (p->d_defer) (void)hipFree(p->d_defer);
   delete p;
 }
 
@@ -813,24 +799,6 @@ int mi_rtj_plan_spec_stats(mi_rtj_plan* p, int* proven, long long* walkers, long
   return MI_RTJ_OK;
 }
 
-int mi_rtj_plan_deferred(mi_rtj_plan* p, long long* blocks) {
-  if (!p || !blocks) return MI_RTJ_ERR_ARG;
-  mi_rtj_ctx* c = p->ctx;
-  *blocks = 0;
-  if (!p->d_defer || !p->defer_words) return MI_RTJ_OK;
-  HIPCHK(c, hipSetDevice(c->device));
-  unsigned long long* d_sum = nullptr;
-  HIPCHK(c, hipMalloc((void**)&d_sum, sizeof(unsigned long long)));
-  HIPCHK(c, hipMemsetAsync(d_sum, 0, sizeof(unsigned long long), c->stream));
-  hipLaunchKernelGGL(k_count_bits, dim3(256), dim3(256), 0, c->stream, p->d_defer, p->defer_words, d_sum);
-  unsigned long long sum = 0;
-  HIPCHK(c, hipMemcpyAsync(&sum, d_sum, sizeof(sum), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  (void)hipFree(d_sum);
-  *blocks = (long long)sum;
-  return MI_RTJ_OK;
-}
-
 #ifdef MIRTJ_STAMPS
 // diagnostic builds only (not declared in include/mi_rtjpeg.h): cycles per k_decode section since the last call
 extern "C" int mi_rtj_debug_stamps(unsigned long long out[16]) {
@@ -872,7 +840,6 @@ int decode_one_launch(mi_rtj_ctx* c, const uint8_t* pkt, size_t len) {
     c->single = new mi_rtj_plan();
     c->single->ctx = c;
     c->single->n = 1;
-    c->single->defer_on = false;  // one packet: a second launch costs more than idle lanes
     c->single->h_frames.resize(1);
     // the A/B switches of the index are read once per decoder, not once per packet
     const char* mode = getenv("MI_RTJ_INDEX");
@@ -1061,7 +1028,6 @@ mi_rtj_pipe* mi_rtj_pipe_create(mi_rtj_ctx* c, int depth, int max_w, int max_h) 
     sl.plan = new mi_rtj_plan();
     sl.plan->ctx = c;
     sl.plan->n = 1;
-    sl.plan->defer_on = false;
     sl.plan->spec_mode = 0;  // one packet per launch: the exact index (a lone walker takes longer than all of it)
     sl.plan->serial_index = mode && strcmp(mode, "serial") == 0;
     sl.plan->emit_walk = em && strcmp(em, "walk") == 0;

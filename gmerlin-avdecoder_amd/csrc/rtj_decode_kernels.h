@@ -462,16 +462,11 @@ constexpr uint32_t kFetchSpan = 72;             // a block's loads stay below it
 // 5 % faster than three at 1080p (A/B over 3..32, tools/ab_iters.sh); the number of waves per part
 // ("slots", decode_slots()) matters as well.
 // ---------------------------------------------------------------------------------------
-#ifndef MIRTJ_DC_DEFER
-#define MIRTJ_DC_DEFER 16
-#endif
-constexpr uint32_t kDcDeferMin = MIRTJ_DC_DEFER;  // "DC only" blocks a group must hold before its other blocks are put off
 constexpr int kCoefWords = kDecThreads * kCoefStride / 2;
 #ifndef MIRTJ_DEC_LDS_PAD
 #define MIRTJ_DEC_LDS_PAD 0
 #endif
 constexpr int kDecLdsWords = kCoefWords + 2 * kSlotTabN + MIRTJ_DEC_LDS_PAD;  // scratch, luma slot table, chroma slot table
-constexpr int kDecListWords = kDecIters * 64 / 2;  // k_decode_list: one 16-bit (iteration, lane) code per block put off
 
 #ifdef MIRTJ_STAMPS  // diagnostic build: where a wave's time goes (shader cycles per section, summed over all waves)
 __device__ unsigned long long g_stamps[16];  // [0..6] luma iterations, [8..14] chroma iterations; [7] waves
@@ -488,15 +483,20 @@ __device__ unsigned long long g_stamps[16];  // [0..6] luma iterations, [8..14] 
   } while (0)
 #endif
 
-// kList == false: k_decode proper.  kList == true: k_decode_list, the same wave over the blocks its k_decode
-// twin put off (`defer`, one 64-bit lane mask per wave and iteration), taken 64 at a time.
-template <bool kList>
+// vector-memory stores every transform variant of decode_wave issues per live wave and iteration (eight rows of 8 bytes
+// per lane); the counted wait behind them is written for exactly this number
+constexpr int kRowStores = 8;
+static_assert(kRowStores == 8, "the wait block of decode_wave spells vmcnt(8)");
+// kRot: a wave takes all three parts of its groups in turn (span 3, batches) / one part (span 1).  kPrev: sessions —
+// unchanged (0xFF) blocks are copied from the previous packet's picture.  Both are compile-time: the instantiation a
+// batch launch runs carries nothing of the other forms (the kernel is short of scalar registers as it is).
+// (Round 2 also held a run-time switched "put the busy blocks of mostly-flat groups off to a second kernel" path
+// here; it was slower — partial-line writes, DESIGN.md — and is gone from the tree.)
+template <bool kRot, bool kPrev>
 __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const FrameDev* __restrict__ frames,
                                             const uint8_t* __restrict__ stream, const QTab* __restrict__ lut,
                                             const uint32_t* __restrict__ blkoff, uint8_t* __restrict__ outbuf,
-                                            unsigned long long* __restrict__ defer, const uint8_t* __restrict__ prev,
-                                            uint32_t span) {
-  // per zig-zag slot: (dequantiser << 16) | scratch byte offset; the luma table, then the chroma table
+                                            const uint8_t* __restrict__ prev) {
   uint32_t* s_tab = s_lds + kCoefWords;
 
   const FrameDev f = frames[blockIdx.y];
@@ -504,7 +504,7 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
   // are dispatched one after the other and (workgroups are dealt round-robin to the 8 XCDs) land on different XCDs —
   // see decode_slots().  span == 3: a wave takes all three parts of its groups in turn (grid.x = slots), so a group's
   // stream bytes and block offsets come over the fabric once instead of three times.
-  const bool rot = !kList && span == 3u;  // wave-uniform
+  constexpr bool rot = kRot;
   const uint32_t slots = rot ? gridDim.x : gridDim.x / 3u;
   const uint32_t slot = rot ? blockIdx.x : blockIdx.x / 3u, part0 = rot ? 0u : blockIdx.x - slot * 3u;
   const uint32_t ngroups = (f.nmb + (uint32_t)kMbPerGroup - 1u) / (uint32_t)kMbPerGroup;
@@ -536,29 +536,6 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
   uint32_t tab_a = lds_address(s_tab) + (chroma ? 4u * (uint32_t)kSlotTabN : 0u);
   int ca_end = (int)tab_a + 4 * 64;  // slot counter (see below) of a finished block
   const uint8_t* data = stream + f.data_off;
-  unsigned long long* my_defer =
-      defer ? defer + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (size_t)kDecIters : nullptr;
-
-  // ---- k_decode_list: the blocks put off, in order, as (iteration << 6 | lane) codes in LDS ----
-  uint32_t n_listed = 0;
-  uint16_t* s_list = (uint16_t*)(s_lds + kDecLdsWords);
-  if (kList) {
-    unsigned long long mine = lane < kDecIters ? my_defer[lane] : 0ull;
-    uint32_t before = 0;
-#pragma unroll
-    for (int i = 0; i < kDecIters; i++) {
-      const unsigned long long m = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(mine >> 32), i) << 32) |
-                                   (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, i);  // wave-uniform
-      if (m >> lane & 1ull) {
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        s_list[before + rank] = (uint16_t)((uint32_t)i << 6 | (uint32_t)lane);
-      }
-      before += (uint32_t)__builtin_popcountll(m);
-    }
-    n_listed = before;
-    if (n_listed == 0u) return;
-    __syncthreads();
-  }
   // iteration `it` of this wave: which group, which block of it, and is there one (per lane)
   struct Src {
     uint32_t grp, dmb, kblk, mb, part;  // part: wave-uniform
@@ -566,43 +543,23 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
   };
   auto source = [&](uint32_t it) -> Src {
     Src r;
-    if (!kList) {
-      uint32_t g = it;
-      r.part = part0;
-      if (rot) {
-        g = it / 3u;
-        r.part = it - 3u * g;
-      }
-      r.grp = slot + g * slots;
-      r.dmb = r.part == 2u ? (uint32_t)(lane & 31) : (uint32_t)(lane >> 1);
-      r.kblk = r.part == 2u ? 4u + (uint32_t)(lane >> 5) : 2u * r.part + (uint32_t)(lane & 1);
-      r.mb = r.grp * (uint32_t)kMbPerGroup + r.dmb;
-      r.valid = g < (uint32_t)kDecIters && r.mb < f.nmb;
-    } else {
-      r.part = part0;
-      const uint32_t e = it * 64u + (uint32_t)lane;
-      r.valid = e < n_listed;
-      const uint32_t code = r.valid ? (uint32_t)s_list[e] : 0u;
-      const uint32_t ls = code & 63u;
-      r.grp = slot + (code >> 6) * slots;
-      r.dmb = chroma ? ls & 31u : ls >> 1;
-      r.kblk = chroma ? 4u + (ls >> 5) : 2u * part0 + (ls & 1u);
-      r.mb = r.grp * (uint32_t)kMbPerGroup + r.dmb;
+    uint32_t g = it;
+    r.part = part0;
+    if (rot) {
+      g = it / 3u;
+      r.part = it - 3u * g;
     }
+    r.grp = slot + g * slots;
+    r.dmb = r.part == 2u ? (uint32_t)(lane & 31) : (uint32_t)(lane >> 1);
+    r.kblk = r.part == 2u ? 4u + (uint32_t)(lane >> 5) : 2u * r.part + (uint32_t)(lane & 1);
+    r.mb = r.grp * (uint32_t)kMbPerGroup + r.dmb;
+    r.valid = g < (uint32_t)kDecIters && r.mb < f.nmb;
     return r;
   };
   auto more_after = [&](uint32_t it) -> bool {  // wave-uniform: is there an iteration it + 1
-    if (kList) return (it + 1u) * 64u < n_listed;
     const uint32_t g = rot ? (it + 1u) / 3u : it + 1u;
     return g < (uint32_t)kDecIters && slot + g * slots < ngroups;
   };
-
-  // ---- "DC only" blocks as the encoder writes them: DC, bt8 zero bytes, then one run over the other 63 - bt8 slots
-  // (RTjpeg_b2s, lib/RTjpeg.c:109-155: a run is the byte 63 + length).  Such a block is the pixel
-  // clamp((int16(DC * q0) + 4) >> 3) 64 times over: every term of both passes but the DC path is zero
-  // (lib/RTjpeg.c:2223-2238 is the reference's own shortcut for it).  The test reads the block's first 16 bytes.
-  const bool dc_test = !kList && !rot && my_defer != nullptr && bt8 <= 14u;  // (the host never asks for both)
-  const int q_dc = chroma ? qt.ciqt[0] : qt.liqt[0];  // (dc_test: the part is fixed)
 
   // the dword that holds stream byte `p` and the four after it, bytes at or past data_len read as 0;
   // `inside`: every lane's loads are known to lie inside the packet
@@ -660,7 +617,7 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
     uint32_t mx, my_;
     const uint32_t mbw = f.mbw, mb0 = grp * (uint32_t)kMbPerGroup;
     const uint32_t gy = mb0 / mbw, gx = mb0 - gy * mbw;  // uniform in k_decode
-    if (!kList && mbw >= (uint32_t)kMbPerGroup) {
+    if (mbw >= (uint32_t)kMbPerGroup) {
       const bool wrap = gx + dmb >= mbw;
       mx = wrap ? gx + dmb - mbw : gx + dmb;
       my_ = wrap ? gy + 1u : gy;
@@ -711,30 +668,7 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
     // unchanged block: previous pixels stay (lib/RTjpeg.c:2704)
     const bool live_any = valid && (__builtin_amdgcn_alignbyte(d1, d0, sh) & 0xFFu) != 0xFFu;
 
-    // ---- enough "DC only" blocks in this group?  Then those are filled in at once and the others put off: they
-    // are taken 64 at a time by k_decode_list, instead of a transform round here with most lanes idle ----
-    bool dc_only = false, put_off = false;
-    if (dc_test) {
-      // byte masks / expected bytes, wave-uniform (worked out here, on the path that uses them, so that they do not
-      // occupy eight scalar registers across the loop of every launch)
-      unsigned long long dcm_lo = 0, dcm_hi = 0, dcp_lo = 0, dcp_hi = 0;
-      {
-        const uint32_t nb1 = bt8 + 2u;  // bytes 0 .. bt8+1 take part (byte 0, DC, is masked out again)
-        dcm_lo = nb1 >= 8u ? ~0ull : (1ull << (8u * nb1)) - 1ull;
-        dcm_hi = nb1 > 8u ? (nb1 >= 16u ? ~0ull : (1ull << (8u * (nb1 - 8u))) - 1ull) : 0ull;
-        dcm_lo &= ~0xFFull;
-        const unsigned long long run = 126ull - bt8;
-        if (bt8 + 1u < 8u) dcp_lo = run << (8u * (bt8 + 1u));
-        else dcp_hi = run << (8u * (bt8 + 1u - 8u));
-      }
-      const unsigned long long b_lo = (unsigned long long)__builtin_amdgcn_alignbyte(d2, d1, sh) << 32 |
-                                      __builtin_amdgcn_alignbyte(d1, d0, sh);
-      const unsigned long long b_hi = (unsigned long long)__builtin_amdgcn_alignbyte(d4, d3, sh) << 32 |
-                                      __builtin_amdgcn_alignbyte(d3, d2, sh);
-      dc_only = live_any && (((b_lo & dcm_lo) ^ dcp_lo) | ((b_hi & dcm_hi) ^ dcp_hi)) == 0ull;
-      put_off = (uint32_t)__builtin_popcountll(__ballot(dc_only)) >= kDcDeferMin;  // wave-uniform
-    }
-    const bool live_blk = live_any && !put_off;  // the lanes of this iteration's transform round, if there is one
+    const bool live_blk = live_any;  // the lanes of this iteration's transform round
 
     if (live_blk) {
       // ---- stream -> dequantised coefficients, int16, transposed (lib/RTjpeg.c:157-186) ----
@@ -825,7 +759,7 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
 
     // ---- sessions with packets in flight give every packet a picture of its own: its unchanged (0xFF) blocks are
     // then fetched from the previous packet's picture (`prev`), which is what "left as it was" means there ----
-    if (prev) {  // wave-uniform
+    if (kPrev) {
       const bool keep = valid && !live_any;
       if (keep) {
         uint32_t o = block_offset(grp, dmb, kblk, mb);
@@ -890,6 +824,9 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
         }
       }
       lo = !__any(hi != 0u);
+#ifdef MIRTJ_EXP_FIXED_PATHS  // timing experiments on wrong data: the paths the bench content takes, whatever the scratch holds
+      lo = chroma;
+#endif
       if (chroma) try_lo_c = lo;
       else try_lo_y = lo;
     }
@@ -920,35 +857,25 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
         put_packed(o);
       };
 
-      if (put_off) {
-        // ---- this group's DC-only blocks: one pixel value, eight rows of it; the other live blocks are left to
-        // k_decode_list (their lane mask goes out below) ----
-        if (dc_only) {
-          const uint32_t b0 = __builtin_amdgcn_alignbyte(d1, d0, sh) & 0xFFu;
-          const int v = (int)(int16_t)(b0 * (uint32_t)q_dc) + 4;  // the product is stored as int16 (lib/RTjpeg.c:163)
-          const uint32_t p1 = px(v);
-          const uint32_t p4 = p1 * 0x01010101u;
-          typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-          u32x2_t ov;
-          ov.x = p4;
-          ov.y = p4;
-#pragma unroll
-          for (int r = 0; r < 8; r++) {
-            __builtin_nontemporal_store(ov, (u32x2_t*)(plane + off32));
-            plane += stride;
-          }
-        }
-      } else if (lo) {
+      if (lo) {
         // rows 0-3 of the column pairs (0, 1) and (2, 3)
         const uint4 qa = my[0], qb = my[2];
         // anything in row 3 or column 3?  (the lanes of this branch: those with a live block)
         const uint32_t t3 = qa.w | qb.w | ((qb.x | qb.y | qb.z) & 0xFFFF0000u);
+#ifdef MIRTJ_EXP_FIXED_PATHS
+        if (true || !__any(t3 != 0u)) {
+#else
         if (!__any(t3 != 0u)) {
+#endif
           // ---- three-input transform: columns 0-2 in, rows of three in ----
 #if MIRTJ_PK_IDCT
           const bool fits = __all(pk_range_lo3(qa, qb, KP));
           MIRTJ_STAMP(5);  // coordinates, scratch reads, 16-bit range test
+#ifdef MIRTJ_EXP_PK_ONLY
+          if (true) {
+#else
           if (fits) {
+#endif
             // two columns, then two rows, to a register (rtj_idct_pk.h)
             uint32_t ya[8], yb[8];
             idct8_pk_lo3_col<true>(qa.x, qa.y, qa.z, ya, KP);   // columns 0, 1
@@ -962,6 +889,7 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
             }
           } else
 #endif
+#ifndef MIRTJ_EXP_PK_ONLY
           {
             int ws[8][3];
 #if MIRTJ_ASM_IDCT
@@ -999,8 +927,12 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
             }
 #endif
           }
+#else
+          {}
+#endif  // MIRTJ_EXP_PK_ONLY
         } else {
           // ---- four-input transform: columns 0-3 in, rows of four in ----
+#ifndef MIRTJ_EXP_PK_ONLY
           int ws[8][4];
 #pragma unroll
           for (int c = 0; c < 4; c++) {
@@ -1019,6 +951,7 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
             idct8_lo(ws[r][0], ws[r][1], ws[r][2], ws[r][3], y);
             put_row(y);
           }
+#endif
         }
       } else {
         bool packed = false;
@@ -1052,6 +985,7 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
           }
         }
 #endif
+#ifndef MIRTJ_EXP_PK_ONLY
         if (!packed) {
           // ---- column pass: column c is one half of the 16-byte pieces c & ~1 (rows 0-3) and (c & ~1) + 1 (rows 4-7) ----
           // Two rounds, rows 0-3 and rows 4-7, each with a column pass of its own: this path is the rare one (a block
@@ -1106,30 +1040,23 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
           }
 #endif
         }
+#endif  // MIRTJ_EXP_PK_ONLY
       }
     }
     MIRTJ_STAMP(3);  // coordinates, transform, row stores
-    // the lanes put off, for k_decode_list: one mask per iteration (the buffer is zeroed before every launch)
-    const unsigned long long m_off = __ballot(live_any && put_off && !dc_only);
-    if (put_off && lane == 0) my_defer[it] = m_off;
     if (!have_n) break;
-    // Every transform variant ends with eight row stores, the fill of DC-only blocks is eight stores and the mask
-    // one more, so behind the join "all but the 8 (9) youngest operations" is exactly "everything requested before
-    // the transform" — unless no lane had a live block: such a wave stored nothing and waits for all there is.
+    // Every transform variant ends with kRowStores row stores, so behind the join "all but the kRowStores youngest
+    // operations" is exactly "everything requested before the transform" — unless no lane had a live block: such a wave
+    // stored nothing and waits for all there is.  (kRowStores sits next to the stores it counts: put_packed above.)
     {
-      const uint32_t younger = put_off ? 9u : __ballot(live_any) != 0ull ? 8u : 0u;
+      const uint32_t younger = __ballot(live_any) != 0ull ? (uint32_t)kRowStores : 0u;
       asm volatile(
           "s_cmp_eq_u32 %4, 8\n\t"
           "s_cbranch_scc1 .Lmirtj_w8_%=\n\t"
-          "s_cmp_eq_u32 %4, 9\n\t"
-          "s_cbranch_scc1 .Lmirtj_w9_%=\n\t"
           "s_waitcnt vmcnt(0)\n\t"
           "s_branch .Lmirtj_arrived_%=\n"
           ".Lmirtj_w8_%=:\n\t"
-          "s_waitcnt vmcnt(8)\n\t"
-          "s_branch .Lmirtj_arrived_%=\n"
-          ".Lmirtj_w9_%=:\n\t"
-          "s_waitcnt vmcnt(9)\n"
+          "s_waitcnt vmcnt(8)\n"
           ".Lmirtj_arrived_%=:"
           : "+v"(nb0), "+v"(nb1), "+v"(nb2), "+v"(pos_nn)
           : "s"(younger)
@@ -1160,40 +1087,18 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
 #endif
 }
 
-// k_decode: see above.  `defer` = nullptr: no group's blocks are put off (every live block is transformed here).
-// `prev` = nullptr: unchanged (0xFF) blocks keep what the output buffer holds; else they are copied from the picture
-// at `prev` (same layout as the output buffer: frame i of the plan at prev + its out_off).
+// k_decode<kRot, kPrev>: see above.  kRot: grid (slots, frames), a wave takes all three parts of its groups; else grid
+// (3 * slots, frames).  kPrev false: unchanged (0xFF) blocks keep what the output buffer holds; true: they are copied
+// from the picture at `prev` (same layout as the output buffer: frame i of the plan at prev + its out_off).
+template <bool kRot, bool kPrev>
 __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const FrameDev* __restrict__ frames,
                                                          const uint8_t* __restrict__ stream,
                                                          const QTab* __restrict__ lut,
                                                          const uint32_t* __restrict__ blkoff,
                                                          uint8_t* __restrict__ outbuf,
-                                                         unsigned long long* __restrict__ defer,
-                                                         const uint8_t* __restrict__ prev, uint32_t span) {
+                                                         const uint8_t* __restrict__ prev) {
   __shared__ __attribute__((aligned(16))) uint32_t s_lds[kDecLdsWords];
-  decode_wave<false>(s_lds, frames, stream, lut, blkoff, outbuf, defer, prev, span);
-}
-
-// k_decode_list: same grid; the wave (slot, part, frame) takes the blocks its k_decode twin put off, 64 per round —
-// block starts and destinations follow from (iteration, lane) as in k_decode, so the list is 8 bytes per wave and
-// iteration.  Rows are stored 8 bytes per lane at unrelated addresses (the blocks are no longer neighbours).
-__global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode_list(const FrameDev* __restrict__ frames,
-                                                              const uint8_t* __restrict__ stream,
-                                                              const QTab* __restrict__ lut,
-                                                              const uint32_t* __restrict__ blkoff,
-                                                              uint8_t* __restrict__ outbuf,
-                                                              unsigned long long* __restrict__ defer) {
-  __shared__ __attribute__((aligned(16))) uint32_t s_lds[kDecLdsWords + kDecListWords];
-  decode_wave<true>(s_lds, frames, stream, lut, blkoff, outbuf, defer, nullptr, 1u);
-}
-
-// set bits of a word array (mi_rtj_plan_deferred: blocks put off by the last k_decode)
-__global__ __launch_bounds__(256) void k_count_bits(const unsigned long long* __restrict__ w, size_t n,
-                                                     unsigned long long* __restrict__ sum) {
-  unsigned long long acc = 0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    acc += (unsigned long long)__builtin_popcountll(w[i]);
-  if (acc) atomicAdd(sum, acc);
+  decode_wave<kRot, kPrev>(s_lds, frames, stream, lut, blkoff, outbuf, prev);
 }
 
 }  // namespace mirtj

@@ -27,6 +27,15 @@ namespace mirtj {
 // wave-uniform constants the blocks take as operands: FIX_1_414213562 = 362, FIX_1_847759065 = 473,
 // -FIX_2_613125930 = -669, FIX_1_082392200 = 277 (lib/RTjpeg.c:1196-1199) in scalar registers; 128 (MULTIPLY's
 // rounding term, :1206) and 235 (RL's upper bound, :1205) in vector registers (a VOP3 takes one scalar operand).
+// Where the transform's multipliers and byte selectors live.  They are wave-uniform, so left to itself the compiler
+// keeps them in scalar registers — of which k_decode has too few: round 2's kernel paid for 50 spilled scalars in
+// v_writelane / v_readlane, vector instructions of the expensive class.  The kernel has vector registers to spare below
+// the 128 that four waves per SIMD allow, so the constants are vector operands ("v"); -DMIRTJ_K_IN_SGPR is the A/B.
+#ifdef MIRTJ_K_IN_SGPR
+#define MIRTJ_KREG(x) "s"(x)
+#else
+#define MIRTJ_KREG(x) "v"(x)
+#endif
 struct IdctK {
   int k362, k473, km669, k277;  // scalar
   int c128, c235;               // vector
@@ -130,7 +139,7 @@ struct IdctK {
 #endif
 
 #define MIRTJ_K_OPERANDS \
-  [k362] "s"(K.k362), [k473] "s"(K.k473), [km669] "s"(K.km669), [k277] "s"(K.k277), [c128] "v"(K.c128), [c235] "v"(K.c235)
+  [k362] MIRTJ_KREG(K.k362), [k473] MIRTJ_KREG(K.k473), [km669] MIRTJ_KREG(K.km669), [k277] MIRTJ_KREG(K.k277), [c128] "v"(K.c128), [c235] "v"(K.c235)
 
 // ---- row pass on eight int32 values + descale, clamp, pack: one row of the block as two dwords ----
 __device__ __forceinline__ uint2 idct8_row_px(int x0, int x1, int x2, int x3, int x4, int x5, int x6, int x7,

@@ -67,7 +67,7 @@ __device__ __forceinline__ IdctPK idct_pk_constants() {
 }
 
 #define MIRTJ_PK_OPERANDS                                                                                        \
-  [k362] "s"(K.k362), [k473] "s"(K.k473), [km669] "s"(K.km669), [k277] "s"(K.k277), [selm] "s"(K.sel_m),          \
+  [k362] MIRTJ_KREG(K.k362), [k473] MIRTJ_KREG(K.k473), [km669] MIRTJ_KREG(K.km669), [k277] MIRTJ_KREG(K.k277), [selm] MIRTJ_KREG(K.sel_m),          \
       [c128] "v"(K.c128)
 
 #define MIRTJ_PK_ADD(D, A, B) "v_pk_add_i16 " D ", " A ", " B "\n\t"
@@ -181,7 +181,7 @@ __device__ __forceinline__ void idct8_pk_row_px(uint32_t (&ya)[4], uint32_t (&yb
       MIRTJ_PK_PX_PACK("%[x2]", "%[x3]", "%[x5]", "%[t0]", "%[x7]", "%[x0]", "%[x4]", "%[x6]")
       : [x0] "=&v"(x0), [x2] "=&v"(x2), [x4] "=&v"(x4), [x6] "=&v"(x6), [t0] "+v"(a0), [t1] "+v"(a1), [pl] "+v"(a2),
         [ph] "+v"(a3), [x1] "+v"(b0), [x3] "+v"(b1), [x5] "+v"(b2), [x7] "+v"(b3)
-      : MIRTJ_PK_OPERANDS, [selt] "s"(K.sel_t), [sello] "s"(K.sel_lo), [selhi] "s"(K.sel_hi), [c235] "v"(K.c235));
+      : MIRTJ_PK_OPERANDS, [selt] MIRTJ_KREG(K.sel_t), [sello] MIRTJ_KREG(K.sel_lo), [selhi] MIRTJ_KREG(K.sel_hi), [c235] "v"(K.c235));
   // MIRTJ_PK_PX_PACK leaves the rows in the registers of y1 y3 y5 y7 = x3 t0 x0 x6
   a = make_uint2(b1, x0);
   b = make_uint2(a0, x6);
@@ -243,7 +243,7 @@ __device__ __forceinline__ void idct8_pk_lo3_row_px(uint32_t ya0, uint32_t ya1, 
       MIRTJ_PK_PX_PACK("%[e0]", "%[e1]", "%[e2]", "%[a]", "%[b]", "%[x1]", "%[z]", "%[x0]")
       : [x0] "=&v"(x0), [a] "=&v"(a), [m] "=&v"(m), [z] "=&v"(z), [b] "=&v"(b), [e0] "=&v"(e0), [e1] "=&v"(e1),
         [e2] "=&v"(e2), [pl] "+v"(ya0), [x1] "+v"(ya1), [x2] "+v"(yb0), [ph] "+v"(yb1)
-      : MIRTJ_PK_OPERANDS, [selt] "s"(K.sel_t), [sello] "s"(K.sel_lo), [selhi] "s"(K.sel_hi), [c235] "v"(K.c235));
+      : MIRTJ_PK_OPERANDS, [selt] MIRTJ_KREG(K.sel_t), [sello] MIRTJ_KREG(K.sel_lo), [selhi] MIRTJ_KREG(K.sel_hi), [c235] "v"(K.c235));
   // rows in the registers of y1 y3 y5 y7 = e1 a x1 x0
   ra = make_uint2(e1, ya1);
   rb = make_uint2(a, x0);
@@ -252,7 +252,7 @@ __device__ __forceinline__ void idct8_pk_lo3_row_px(uint32_t ya0, uint32_t ya1, 
 // acc + (32768 - |lo half|) + (32768 - |hi half|), halves read as int16
 __device__ __forceinline__ uint32_t pk_sad(uint32_t w, uint32_t acc, const IdctPK& K) {
   uint32_t r;
-  asm("v_sad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(w), "s"(K.sadk), "v"(acc));
+  asm("v_sad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(w), MIRTJ_KREG(K.sadk), "v"(acc));
   return r;
 }
 

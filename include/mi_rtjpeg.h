@@ -157,10 +157,6 @@ int mi_rtj_plan_spec_stats(mi_rtj_plan *plan, int *proven, long long *walkers, l
  * before its chunk (the short or the long form; 0: the speculative index is not used for this plan),
  * *paused_launches = decodes left that go straight to the exact kernels.  Synchronises the instance's stream. */
 int mi_rtj_plan_spec_lead(mi_rtj_plan *plan, int *lead_bytes, int *paused_launches);
-/* After a decode: *blocks = 8x8 blocks that k_decode left to k_decode_list in that decode (groups that held enough
- * DC-only blocks fill those in at once and put their other blocks off; 0 also when the plan never puts blocks off:
- * small plans, the one-packet path, MI_RTJ_DEFER=0).  Synchronises the instance's stream. */
-int mi_rtj_plan_deferred(mi_rtj_plan *plan, long long *blocks);
 /* Test hook: copy the plan's block-start index (relative to each packet's first data byte,
  * nblocks+1 entries per frame, frames back to back) to the host after a decode. */
 int mi_rtj_plan_read_index(mi_rtj_plan *plan, uint32_t *dst, size_t max_entries);

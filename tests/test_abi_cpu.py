@@ -60,7 +60,7 @@ def test_hand_issued_loads_of_k_decode_are_not_touched_before_their_wait(tmp_pat
     import sys
     csrc = os.path.join(ROOT, "gmerlin-avdecoder_amd", "csrc")
     # the shipped build and the test build of tests/test_gpu_variant_paths.py (its own flags, its own register allocation)
-    for name, flags in (("product", []), ("general", ["-DMIRTJ_TEST_GENERIC_PATHS", "-DMIRTJ_DC_DEFER=1"])):
+    for name, flags in (("product", []), ("general", ["-DMIRTJ_TEST_GENERIC_PATHS"])):
         d = tmp_path / name
         d.mkdir()
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",

@@ -1,8 +1,7 @@
 """The kernels specialise for what real streams look like (raw-byte counts 0/4/8/9 known at compile
 time, unmasked loads when a wave reads inside its packet).  A second build of the same library with
--DMIRTJ_TEST_GENERIC_PATHS always takes the general paths instead (and, with -DMIRTJ_DC_DEFER=1, puts a group's
-other blocks off as soon as one of its blocks is DC only); this test runs the parity checks on it, in a child
-process (one library per process)."""
+-DMIRTJ_TEST_GENERIC_PATHS always takes the general paths instead; this test runs the parity checks on it, in a
+child process (one library per process)."""
 import os
 import subprocess
 import sys
@@ -61,7 +60,7 @@ def test_general_kernel_paths_match_the_oracle(tmp_path):
     bld = __import__("importlib").import_module("gmerlin-avdecoder_amd.build")
     lib = bld.build_test_variant()  # built by __graft_entry__.build(); rebuilt here only if missing or stale
     tests = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, MI_RTJ_LIB=lib, MI_RTJ_DEFER="1")  # the variant puts blocks off at the first DC-only block
+    env = dict(os.environ, MI_RTJ_LIB=lib)
     r = subprocess.run([sys.executable, "-c", CHILD, tests], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "variant ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 

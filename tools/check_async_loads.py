@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
 """Checks the compiled k_decode for the one thing the compiler does not know (csrc/rtj_decode_kernels.h): the
 registers that the hand-issued loads of the group loop are filling must not be touched between the loads and the
-hand-placed `s_waitcnt vmcnt(8)` / `vmcnt(0)` block behind the row stores, no other vector-memory instruction than the 8-byte row / mask stores and no compiler-placed vmcnt wait may sit in between.
+hand-placed `s_waitcnt vmcnt(8)` / `vmcnt(0)` block behind the row stores, no other vector-memory instruction than the
+8-byte row stores (scratch_* spill traffic counts on vmcnt too and is refused) and no compiler-placed vmcnt wait may
+sit in between.  Every instantiation of k_decode in the file is checked.
 
     python tools/check_async_loads.py file.s        (hipcc -save-temps device assembly)
 
-Exit status 0 = clean.  Run by tests/test_abi_cpu.py on the cross-compiled kernel."""
+Exit status 0 = clean.  Run by gmerlin-avdecoder_amd/build.py on every library it builds (a finding fails the build)
+and by tests/test_abi_cpu.py."""
 import re
 import sys
 
@@ -25,13 +28,29 @@ def all_vregs(line):
     return out
 
 
-def check(path, kernel="k_decode", fills=4, singles=1):
-    """fills: basic blocks that must hold exactly eight stores (three transform variants + the DC-only fill in
-    k_decode; three in k_decode_list); singles: blocks with one store (the put-off mask)."""
+def kernels_of(path, stem="k_decode"):
+    """(label, first line, end line) of every instantiation of the kernel template `stem` in the file"""
     lines = open(path).read().split("\n")
-    start = next(i for i, l in enumerate(lines) if re.match(r"^_ZN5mirtj\d+" + kernel + r"E.*:", l))
-    end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
-    body = lines[start:end]
+    out = []
+    for i, l in enumerate(lines):
+        m = re.match(r"^(_ZN5mirtj\d+" + stem + r"(?:I\w+?E)?E\w*):", l)
+        if m:
+            end = next(k for k in range(i, len(lines)) if lines[k].startswith(".Lfunc_end"))
+            out.append((m.group(1), i, end))
+    return lines, out
+
+
+def check_all(path, stem="k_decode"):
+    lines, ks = kernels_of(path, stem)
+    if not ks:
+        return [f"{stem}: not found in {path}"]
+    errs = []
+    for name, a, b in ks:
+        errs += check(lines[a:b], name)
+    return errs
+
+
+def check(body, kernel):
     # the hand-issued block: the ASMSTART region that holds global_load_dwordx4 (exactly one, inside the group loop)
     blocks = []
     i = 0
@@ -70,8 +89,8 @@ def check(path, kernel="k_decode", fills=4, singles=1):
             if any("s_waitcnt vmcnt(8)" in x for x in txt):
                 if not any("s_waitcnt vmcnt(0)" in x for x in txt):
                     errs.append(f"line {k}: the wait block has no vmcnt(0) arm for waves that stored nothing")
-                if singles and not any("s_waitcnt vmcnt(9)" in x for x in txt):
-                    errs.append(f"line {k}: the wait block has no vmcnt(9) arm for groups that were put off")
+                if any(re.search(r"vmcnt\((?!0\)|8\))", x) for x in txt):
+                    errs.append(f"line {k}: the wait block has an arm other than vmcnt(8) / vmcnt(0)")
                 wait_at = k
                 break
     if wait_at is None:
@@ -100,7 +119,7 @@ def check(path, kernel="k_decode", fills=4, singles=1):
         if op.startswith("global_store"):
             cur["stores"] += 1
             continue
-        if op.startswith(("global_load", "buffer_", "flat_", "global_atomic")):
+        if op.startswith(("global_load", "buffer_", "flat_", "global_atomic", "scratch_")):
             errs.append(f"line {k}: vector-memory instruction '{t}' between the loads and their wait")
         if op.startswith("s_cbranch") and not inasm:
             cur["succ"].append(t.split()[1])
@@ -118,9 +137,9 @@ def check(path, kernel="k_decode", fills=4, singles=1):
             errs.append(f"line {k}: '{t}' touches pending v{sorted(touched)}")
     blocks_.append(cur)
     # How many stores lie on a path is decided by wave-uniform branches this script does not interpret (the three
-    # transform variants, the DC-only fill; the compiler also sinks a variant's last store into a shared block), so
-    # only what can be told from the text is checked: every store is a row store or the mask (8 bytes), and no basic
-    # block holds more than a variant's eight.  That each executed path issues the 8 or 9 stores the counted wait
+    # transform variants; the compiler also sinks a variant's last store into a shared block), so
+    # only what can be told from the text is checked: every store is a row store (8 bytes), and no basic
+    # block holds more than a variant's eight.  That each executed path issues the 8 stores the counted wait
     # assumes is what the parity tests show at run time: a wait that is one short hands the parser stale registers.
     per_block = [b["stores"] for b in blocks_]
     if max(per_block) > 8 or sum(per_block) < 8:
@@ -133,7 +152,7 @@ def check(path, kernel="k_decode", fills=4, singles=1):
 
 
 if __name__ == "__main__":
-    e = check(sys.argv[1], "k_decode", 4, 1) + check(sys.argv[1], "k_decode_list", 3, 0)
+    e = check_all(sys.argv[1], "k_decode")
     for x in e:
         print("ASYNC-LOAD CHECK:", x)
     print("pending-load check:", "clean" if not e else f"{len(e)} problem(s)")
