@@ -27,14 +27,15 @@ namespace mirtj {
 // wave-uniform constants the blocks take as operands: FIX_1_414213562 = 362, FIX_1_847759065 = 473,
 // -FIX_2_613125930 = -669, FIX_1_082392200 = 277 (lib/RTjpeg.c:1196-1199) in scalar registers; 128 (MULTIPLY's
 // rounding term, :1206) and 235 (RL's upper bound, :1205) in vector registers (a VOP3 takes one scalar operand).
-// Where the transform's multipliers and byte selectors live.  They are wave-uniform, so left to itself the compiler
-// keeps them in scalar registers — of which k_decode has too few: round 2's kernel paid for 50 spilled scalars in
-// v_writelane / v_readlane, vector instructions of the expensive class.  The kernel has vector registers to spare below
-// the 128 that four waves per SIMD allow, so the constants are vector operands ("v"); -DMIRTJ_K_IN_SGPR is the A/B.
-#ifdef MIRTJ_K_IN_SGPR
-#define MIRTJ_KREG(x) "s"(x)
-#else
+// Where the transform's multipliers and byte selectors live.  They are wave-uniform and the compiler keeps them in scalar
+// registers ("s").  k_decode is short of those (round 2's kernel paid for 50 spilled scalars in v_writelane / v_readlane;
+// the batch instantiation is down to 10 since the launch shape became a template parameter), and it has vector
+// registers to spare below the 128 that four waves per SIMD allow, so -DMIRTJ_K_IN_VGPR makes them vector operands:
+// measured, that leaves 7 spills instead of 10 and is 0.5 % SLOWER (profiles/r03/ab_spills.txt) — the default stays "s".
+#ifdef MIRTJ_K_IN_VGPR
 #define MIRTJ_KREG(x) "v"(x)
+#else
+#define MIRTJ_KREG(x) "s"(x)
 #endif
 struct IdctK {
   int k362, k473, km669, k277;  // scalar

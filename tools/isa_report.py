@@ -37,7 +37,7 @@ def device_asm(cflags, keep=None):
 
 def demangle(names):
     try:
-        r = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"] + names, capture_output=True, text=True)
+        r = subprocess.run(["c++filt"] + names, capture_output=True, text=True)
         out = r.stdout.split("\n")
         return {n: (out[i] if i < len(out) and out[i] else n) for i, n in enumerate(names)}
     except OSError:
