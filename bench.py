@@ -30,8 +30,12 @@ Rank 0 prints ONE JSON line: the contract fields plus
   "roofline_valu": the same kernel against the vector-issue roof: instructions per launch (PMC) x measured cost per
                    instruction / measured time
   "cpu_baseline":  the reference's lib/RTjpeg.c (oracle/_ref, kind "reference") or the oracle port, one thread, timed
-                   on this box on a bounded sample of the same packets; "cpu_baseline_all_cores": one decoder per core
-  "parity_checked" / "parity_mismatches": frames of this run compared with the CPU decoder, all of the sample
+                   on this box (rank 0's host, whatever N) on a bounded sample of the same packets;
+                   "cpu_baseline_all_cores": one decoder per core
+  "parity_checked" / "parity_mismatches": frames of this run compared with the CPU decoder: EVERY rank copies a sample
+                   of its own output to the host, has its own CPU processes decode the same packets and feeds the counts
+                   into the one reduction of the path (parity_checked = N x sample)
+  "by_batch":      (N = 1) the same step at 256 / 1024 / 4096 frames per launch next to the default 16384
 The process exits non-zero when a compared frame differs.
 """
 import argparse
@@ -72,7 +76,9 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU legs (and with them the parity check)")
     ap.add_argument("--no-stress", action="store_true", help="skip the short second measurement on noisy content")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (plugin harness) measurement")
-    ap.add_argument("--verify-frames", type=int, default=256, help="frames of the batch compared with the CPU decoder")
+    ap.add_argument("--verify-frames", type=int, default=None,
+                    help="frames of EACH rank's batch compared with the CPU decoder (default 256 at one GPU, 64 per rank otherwise; at least 32)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the batch-size sweep (by_batch)")
     ap.add_argument("--selftest-ranks", action="store_true",
                     help="no GPU work: every rank reports a dummy shard through the same reduction (launcher test)")
     return ap.parse_args()
@@ -142,10 +148,26 @@ def _cpu_worker(args):
     return kind, digests, done, dt
 
 
-def cpu_legs(pkts, w, h, budget_s, gpu_digests):
-    """(cpu_baseline, cpu_baseline_all_cores, frames compared, mismatches).  The sample is dealt to one process per
-    core this process may use; each decodes its share once for the comparison, then runs the timed loop.  The
-    one-core figure is timed separately, on its own (nothing else running)."""
+def parity_check(pkts, w, h, gpu_digests, procs):
+    """(frames compared, mismatches): this rank's sample decoded by `procs` CPU processes of this rank's own host
+    process (one decoder each, no timing), digests against the GPU's."""
+    import multiprocessing as mp
+    procs = max(1, min(procs, len(pkts)))
+    shares = [pkts[i::procs] for i in range(procs)]
+    with mp.get_context("spawn").Pool(procs) as pool:
+        res = pool.map(_cpu_worker, [(s, w, h, 0.0) for s in shares])
+    mism, checked = 0, 0
+    for i, (_, digs, _, _) in enumerate(res):
+        for j, d in enumerate(digs):
+            k = i + j * procs
+            checked += 1
+            mism += int(d != gpu_digests[k])
+    return checked, mism
+
+
+def cpu_timed_legs(pkts, w, h, budget_s):
+    """(cpu_baseline, cpu_baseline_all_cores), rank 0 only, nothing else running on the host: the one-core figure is
+    timed on its own, then one decoder per core this process may use."""
     import multiprocessing as mp
     cores = max(1, len(os.sched_getaffinity(0)))
     kind, _, done1, dt1 = _cpu_worker((pkts[: min(len(pkts), 16)], w, h, budget_s))
@@ -154,18 +176,13 @@ def cpu_legs(pkts, w, h, budget_s, gpu_digests):
                      f"{dt1:.1f} s, host has {os.cpu_count()} logical cores",
            "mpixels_per_s": round(done1 * w * h / dt1 / 1e6, 1)}
     shares = [pkts[i::cores] for i in range(cores)]
+    shares = [s_ if s_ else pkts[:1] for s_ in shares]
     with mp.get_context("spawn").Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(s, w, h, budget_s) for s in shares])
-    mism, checked = 0, 0
-    for i, (_, digs, _, _) in enumerate(res):
-        for j, d in enumerate(digs):
-            k = i + j * cores
-            checked += 1
-            mism += int(d != gpu_digests[k])
+        res = pool.map(_cpu_worker, [(s_, w, h, budget_s) for s_ in shares])
     allc = {"value": round(sum(r[2] / r[3] for r in res if r[3] > 0), 1), "unit": "frames/s", "cores": cores,
             "kind": kind, "sample": f"{cores} processes, one decoder each, {budget_s:.0f} s, shares of the same "
                                     f"{len(pkts)} packets"}
-    return one, allc, checked, mism
+    return one, allc
 
 
 # --------------------------------------------------------------------------- PMC profile of the same sources
@@ -178,6 +195,15 @@ def kernel_source_digest():
         if name.endswith((".h", ".hip", ".cpp")) and ("kernels" in name or "idct" in name or name == "rtj_common.h"):
             hsh.update(name.encode())
             hsh.update(strip_comments(open(os.path.join(csrc, name), encoding="utf-8").read()).encode())
+    # ... and the launch geometry (grids, spans, walkers per launch: what decides how often bytes are fetched), which
+    # lives on the host side: plan_launch() of mi_rtjpeg.hip, from its first line to the closing brace in column 0
+    host = open(os.path.join(csrc, "mi_rtjpeg.hip"), encoding="utf-8").read()
+    a = host.find("int plan_launch(")
+    b = host.find("\n}\n", a)
+    if a < 0 or b < 0:
+        raise SystemExit("bench.py: plan_launch() not found in mi_rtjpeg.hip: the traffic digest cannot be formed")
+    hsh.update(b"plan_launch")
+    hsh.update(strip_comments(host[a:b]).encode())
     return hsh.hexdigest()[:16]
 
 
@@ -314,10 +340,20 @@ def main():
     r = run_frames(a, dev, rank, n, a.amp, a.steps, a.warmup, barrier, sync_all)
     plan, info, fsz = r["plan"], r["info"], r["fsz"]
 
-    # the only collective of the path: SUM(frames, pixels, mismatches), MAX(elapsed) — a few bytes over RCCL
-    rep = shard.reduce_report(shard.Report(n, n * w * h, 0, r["dt"]), dist, device=red_dev, force=force_dist)
+    # parity, on EVERY rank: a sample of this rank's own output goes to the host and is compared with what CPU
+    # decoders (processes of this rank, its share of the host's cores) make of the same packets
+    pad = int(os.environ.get("MI_RTJ_BENCH_PAD", "0"))
+    pkts, checked, my_mism = [], 0, 0
+    if not a.no_cpu:
+        ns = min(n, max(32, a.verify_frames if a.verify_frames else (256 if world == 1 else 64)))
+        pkts = [dev.d2h(r["d_st"], int(r["pl"][i]), offset=int(r["po"][i])) for i in range(ns)]
+        gpu_digests = [hashlib.sha256(dev.d2h(r["d_out"], fsz, offset=i * (fsz + pad)).tobytes()).hexdigest()[:32]
+                       for i in range(ns)]
+        checked, my_mism = parity_check(pkts, w, h, gpu_digests, max(1, len(os.sched_getaffinity(0)) // world))
+    # the only collective of the path: SUM(frames, pixels, mismatches, frames compared), MAX(elapsed) — a few bytes over RCCL
+    rep = shard.reduce_report(shard.Report(n, n * w * h, my_mism, r["dt"], checked), dist, device=red_dev, force=force_dist)
     tot_frames, dt = rep.frames, rep.elapsed
-    mismatches = 0
+    mismatches = rep.mismatches
     if rank == 0:
         fps = tot_frames * a.steps / dt
         alg_bytes = info["bytes_in"] + info["bytes_out"]  # packet read once + planes written once
@@ -344,7 +380,10 @@ def main():
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "i32", "data": "synthetic",
             "config": {"workload": f"RTjpeg {w}x{h} YUV420 Q={Q} intra-only, {n} distinct frames/GPU resident in HBM "
-                                   f"(BASELINE configs[1]); gradient+noise amp {a.amp}, seed {a.seed}",
+                                   f"(BASELINE configs[1]); content: gradient + noise amp {a.amp}, seed {a.seed}, from the "
+                                   f"device generator k_synth (= tests/rtjlib.py synth_frame: hash-counter noise, gradient "
+                                   f"wrapped mod w+h) — NOT SURVEY 8d's LCG generator; packets within 1 % of its size "
+                                   f"(588 vs 583 kB), digests pinned to the reference encoder on the same frames",
                        "frames_per_gpu": n, "avg_packet_bytes": int(info["bytes_in"] // n),
                        "sharding": "frames, no data-path collective"},
             "mpixels_per_s": round(fps * w * h / 1e6, 1),
@@ -387,16 +426,14 @@ def main():
                         "measured: the share of the 2.4-cycle issue roof the kernel reaches; frac_of_expensive_rate = "
                         "floor_ms_all_mixed / measured: nearly all of k_decode's instructions are of the expensive class "
                         "(its transform runs two values to a register), so this is the roof it sits under"}
-        if world == 1 and not a.no_cpu:
-            ns = min(n, max(1, a.verify_frames))
-            pkts = [dev.d2h(r["d_st"], int(r["pl"][i]), offset=int(r["po"][i])) for i in range(ns)]
-            gpu_digests = [hashlib.sha256(dev.d2h(r["d_out"], fsz, offset=i * (fsz + int(os.environ.get("MI_RTJ_BENCH_PAD", "0")))).tobytes()).hexdigest()[:32]
-                           for i in range(ns)]
-            one, allc, checked, mismatches = cpu_legs(pkts, w, h, a.cpu_seconds, gpu_digests)
+        if not a.no_cpu:
+            # the CPU baseline: rank 0's host, for any N (the other ranks wait at the barrier below, the host is idle)
+            one, allc = cpu_timed_legs(pkts, w, h, a.cpu_seconds)
             out["cpu_baseline"] = one
             out["cpu_baseline_all_cores"] = allc
-            out["parity_checked"] = checked
-            out["parity_mismatches"] = mismatches
+            out["parity_checked"] = rep.checked
+            out["parity_mismatches"] = rep.mismatches
+            out["parity_sample_per_rank"] = checked
             out["speedup_vs_cpu_1core"] = round(fps / one["value"], 1)
             out["speedup_vs_cpu_all_cores"] = round(fps / allc["value"], 1) if allc["value"] else None
         # end to end through the plugin seam (host packets in, host pictures out; SURVEY 8d "End-to-end vs kernel (ii)"):
@@ -405,11 +442,16 @@ def main():
             try:
                 e2e = importlib.import_module("tools.e2e_bench")
                 r2 = e2e.run(w, h, packets=min(n, 64), repeat=16)
+                two = r2.pop("two_streams_two_threads", {})
                 out["end_to_end"] = {"fps": max((v.get("fps", 0) for v in r2.values() if isinstance(v, dict)), default=0),
+                                     "two_streams_fps": two.get("fps"),
                                      "pcie_cap_fps": r2["pcie_cap_fps"], "by_flavour": {k: v for k, v in r2.items() if isinstance(v, dict)},
-                                     "note": "one stream, one host thread, through csrc/video_rtjpeg_mi355x.c; fps = the best "
-                                             "flavour (frame-owning with packets in flight); cap = what the host link gives one picture-sized pinned copy "
-                                             "at a time (38.4 GB/s for 3.1 MB, tools/pcie_probe.py) / picture bytes"}
+                                     "note": "fps: ONE stream, one host thread, through csrc/video_rtjpeg_mi355x.c, the best "
+                                             "flavour (its default build: frame-owning with packets in flight, pictures leaving on "
+                                             "two copy streams); two_streams_fps: two instances on two threads, aggregate; "
+                                             "pcie_cap_fps = what the host link gives ONE picture-sized pinned copy at a time "
+                                             "(38.4 GB/s for 3.1 MB, tools/pcie_probe.py) / picture bytes — the cap of round 2's "
+                                             "sessions, which had one copy out in flight"}
             except Exception as exc:  # the harness is a convenience here, not the measurement
                 out["end_to_end"] = {"error": str(exc)[:200]}
         # what a plain streaming copy kernel sustains on this device (read + write), measured now: the second
@@ -420,6 +462,25 @@ def main():
     plan.close()
     dev.free(r["d_st"])
     dev.free(r["d_out"])
+    barrier()  # ranks other than 0 wait here while rank 0 times the CPU legs
+
+    # the same step at other launch sizes: 3 timed steps each, fresh frames, never part of `value`
+    if world == 1 and rank == 0 and not a.no_sweep:
+        sweep = {}
+        for nb in (256, 1024, 4096):
+            if nb >= n:
+                continue
+            sw = run_frames(a, dev, rank, nb, a.amp, 3, 2, barrier, sync_all)
+            sweep[str(nb)] = {"frames_per_s": round(nb * 3 / sw["dt"], 1),
+                              "kernels_ms": {k: round(v / max(sw["launches"], 1), 4) for k, v in sw["ktimes"].items() if v > 0},
+                              "index": "speculative" if sw["plan"].spec_stats()[1] else "exact"}
+            sw["plan"].close()
+            dev.free(sw["d_st"])
+            dev.free(sw["d_out"])
+        sweep[str(n)] = {"frames_per_s": out["value"], "kernels_ms": {k: v["ms"] for k, v in out["kernels"].items()},
+                         "index": "speculative" if out["speculative_index"]["stream_chunks"] else "exact"}
+        out["by_batch"] = dict(sweep, note="frames per launch -> whole-step frames/s (3 timed steps, 2 warm-up; the last "
+                                           "entry is the headline run)")
 
     # SURVEY.md section 8d's stress variant (noise +-64: 2.3 MB packets, nothing for the speculative index to lock on)
     # as a second, short, clearly labelled measurement; never part of `value`

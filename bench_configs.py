@@ -48,6 +48,59 @@ def _cpu_digests(args):
     return out
 
 
+HBM_PEAK_GBS = 8000.0  # as bench.py
+
+
+def _roofline(ktimes, launches, alg_bytes_per_launch, note):
+    """the bench contract's roofline object for the dominant kernel of a profiled run"""
+    per = {k: v / max(launches, 1) for k, v in ktimes.items() if v > 0}
+    dom = max(per, key=per.get)
+    ach = alg_bytes_per_launch[dom] / (per[dom] * 1e-3) / 1e9 if alg_bytes_per_launch.get(dom) else 0.0
+    return {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "ms_per_launch": round(per[dom], 4),
+            "alg_bytes_per_launch": alg_bytes_per_launch.get(dom), "kernels_ms": {k: round(v, 4) for k, v in per.items()},
+            "note": note}
+
+
+def _cpu_timed(args):
+    """worker: one CPU decoder (the reference's RTjpeg.c when built, else the oracle port) over the packets in order,
+    decode + one frame copy as decode_rtjpeg does, for about `budget` seconds"""
+    pkts, budget = args
+    import time as _t
+    R = _checker()
+    if R.have_reference():
+        kind, codec = "reference", R.RefCodec()
+    else:
+        kind, codec = "port", R.OracleDecoder()
+    pics = {}
+    done, t0 = 0, _t.perf_counter()
+    while True:
+        for p in pkts:
+            w, h = int(p[6]) | (int(p[7]) << 8), int(p[8]) | (int(p[9]) << 8)
+            pic = pics.setdefault((w, h), (np.zeros(w * h * 3 // 2, np.uint8), np.zeros(w * h * 3 // 2, np.uint8)))
+            pp = np.concatenate([p, np.zeros(4096, np.uint8)])
+            if kind == "reference":
+                codec.w, codec.h_ = w, h
+                codec.L.RTjpeg_decompress(codec.h, R._ptr(pp), R._planes_arg(pic[0], w, h))
+            else:
+                codec.decode(pp, pic[0])
+            np.copyto(pic[1], pic[0])
+            done += 1
+            if _t.perf_counter() - t0 > budget:
+                break
+        if _t.perf_counter() - t0 > budget:
+            break
+    return kind, done, _t.perf_counter() - t0
+
+
+def _cpu_baseline(pkts, budget, what):
+    import multiprocessing as mp
+    with mp.get_context("spawn").Pool(1) as pool:  # a process of its own: this one holds the GPU context
+        kind, done, dt = pool.map(_cpu_timed, [(pkts, budget)])[0]
+    return {"value": round(done / dt, 2), "unit": "frames/s", "cores": 1, "kind": kind,
+            "sample": f"{done} decodes ({what}), decode + one frame copy, {dt:.1f} s"}
+
+
 def run_streams4k(a, dev, shard, dist, red_dev, rank, world, barrier, sync_all, force_dist):
     w, h, Q = 3840, 2160, a.quality
     nf = a.frames or 48
@@ -71,9 +124,11 @@ def run_streams4k(a, dev, shard, dist, red_dev, rank, world, barrier, sync_all, 
                 check[tag] = _digest(np.concatenate([y, u, v]))
             got += 1
 
-    ncheck = min(nf, 6)
+    # the whole first lap is compared: every key period of the stream (key_rate 12: the encoder's reference picture is
+    # reset when the key counter wraps, lib/RTjpeg.c:3504-3514) and the pictures after each wrap
+    ncheck = nf
     mine = [None] * ncheck
-    lap(mine)  # first lap: also the warm-up; its first pictures are compared (the stream starts from a blank picture)
+    lap(mine)  # first lap: also the warm-up (the stream starts from a blank picture)
     for _ in range(max(a.warmup - 1, 0)):
         lap()
     barrier()
@@ -84,10 +139,15 @@ def run_streams4k(a, dev, shard, dist, red_dev, rank, world, barrier, sync_all, 
     sync_all()
     barrier()
     dt = time.perf_counter() - t0
+    # kernel times: a lap of its own with profiling on (it costs the submitting thread two event records per kernel)
+    pipe.profile(True)
+    lap()
+    ktimes, launches = pipe.times()
+    pipe.profile(False)
     pipe.close()
     want = _cpu_digests((pkts[:ncheck],))
     mism = sum(int(x != y) for x, y in zip(mine, want))
-    rep = shard.reduce_report(shard.Report(nf, nf * w * h, mism, dt), dist, device=red_dev, force=force_dist)
+    rep = shard.reduce_report(shard.Report(nf, nf * w * h, mism, dt, ncheck), dist, device=red_dev, force=force_dist)
     fps = rep.frames * a.steps / rep.elapsed
     out = {"metric": "RTjpeg 3840x2160 decode frames/sec, in-order streams, host to host", "value": round(fps, 1),
            "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -100,7 +160,14 @@ def run_streams4k(a, dev, shard, dist, red_dev, rank, world, barrier, sync_all, 
                        "sharding": "streams, one per GPU, no data-path collective"},
            "mpixels_per_s": round(fps * w * h / 1e6, 1),
            "pcie_cap_frames_per_s_per_gpu": round(54.6e9 / (w * h * 1.5), 0),  # 12.4 MB pinned copies: tools/pcie_probe.py
-           "parity_checked": rep.frames and ncheck * world, "parity_mismatches": rep.mismatches}
+           "parity_checked": rep.checked, "parity_mismatches": rep.mismatches}
+    if rank == 0:
+        bytes_in = sum(int(p.size) - 12 for p in pkts) / nf
+        alg = {"k_decode": bytes_in + w * h * 1.5, "k_index_summarize": bytes_in, "k_index_emit": bytes_in}
+        out["roofline"] = _roofline(ktimes, launches, alg, "one packet per launch (in-order stream): the path is bound by "
+                                    "the host link, not by this kernel; algorithmic bytes = packet + picture")
+        if not a.no_cpu:
+            out["cpu_baseline"] = _cpu_baseline(pkts, a.cpu_seconds, f"the stream's {nf} 3840x2160 packets in order")
     return out, mism
 
 
@@ -133,8 +200,11 @@ def run_mixed(a, dev, shard, dist, red_dev, rank, world, barrier, sync_all, forc
     oo = np.concatenate([[0], np.cumsum([(s + 255) // 256 * 256 for s in sizes])]).astype(np.uint64)
     d_out = dev.alloc(int(oo[-1]))
     plan = dev.plan(hdrs, po, pl, oo[:-1].copy())
+    info = plan.info()
     for _ in range(a.warmup):
         plan.decode(d_stream, d_out)
+    dev.sync()
+    plan.profile(True)
     barrier()
     sync_all()
     t0 = time.perf_counter()
@@ -143,6 +213,8 @@ def run_mixed(a, dev, shard, dist, red_dev, rank, world, barrier, sync_all, forc
     sync_all()
     barrier()
     dt = time.perf_counter() - t0
+    ktimes, launches = plan.times()
+    plan.profile(False)
     # every picture of this rank against the CPU decoder (one decoder per picture: the plan applies the header state
     # machine in plan order, and so does a fresh CPU decoder given the same packet alone, since every packet carries
     # a non-zero quality)
@@ -156,7 +228,7 @@ def run_mixed(a, dev, shard, dist, red_dev, rank, world, barrier, sync_all, forc
     plan.close()
     dev.free(d_stream)
     dev.free(d_out)
-    rep = shard.reduce_report(shard.Report(len(plist), pixels, mism, dt), dist, device=red_dev, force=force_dist)
+    rep = shard.reduce_report(shard.Report(len(plist), pixels, mism, dt, len(plist)), dist, device=red_dev, force=force_dist)
     fps = rep.frames * a.steps / rep.elapsed
     out = {"metric": "RTjpeg decode frames/sec, mixed batch", "value": round(fps, 1), "unit": "frames/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(rep.elapsed / a.steps * 1e3, 4),
@@ -166,7 +238,13 @@ def run_mixed(a, dev, shard, dist, red_dev, rank, world, barrier, sync_all, forc
                                   f"GPU resident in HBM (BASELINE configs[4])",
                        "frames_total": rep.frames, "sharding": "frames, cyclic, no data-path collective"},
            "mpixels_per_s": round(rep.pixels * a.steps / rep.elapsed / 1e6, 1),
-           "parity_checked": rep.frames, "parity_mismatches": rep.mismatches}
+           "parity_checked": rep.checked, "parity_mismatches": rep.mismatches}
+    if rank == 0:
+        alg = {"k_decode": info["bytes_in"] + info["bytes_out"], "k_index_summarize": info["bytes_in"],
+               "k_index_emit": info["bytes_in"], "k_spec_walk": info["bytes_in"]}
+        out["roofline"] = _roofline(ktimes, launches, alg, "rank 0's plan; algorithmic bytes = packets + pictures of the plan")
+        if not a.no_cpu:
+            out["cpu_baseline"] = _cpu_baseline(plist[:24], a.cpu_seconds, "rank 0's first 24 packets of the mix, in plan order")
     return out, mism
 
 

@@ -31,7 +31,8 @@ EXPORTS = ["mi_rtj_device_count", "mi_rtj_create", "mi_rtj_destroy", "mi_rtj_las
            "mi_rtj_get_tables", "mi_rtj_yuv420_to_rgb", "mi_rtj_encode_stream", "mi_rtj_decode_nocopy",
            "mi_rtj_copy_ceiling", "mi_rtj_plan_spec_stats", "mi_rtj_plan_spec_lead",
            "mi_rtj_plan_step_times", "mi_rtj_pipe_create", "mi_rtj_pipe_destroy", "mi_rtj_pipe_room",
-           "mi_rtj_pipe_pending", "mi_rtj_pipe_submit", "mi_rtj_pipe_next", "mi_rtj_pipe_peek_tag", "mi_rtj_pipe_flush"]
+           "mi_rtj_pipe_pending", "mi_rtj_pipe_submit", "mi_rtj_pipe_next", "mi_rtj_pipe_peek_tag", "mi_rtj_pipe_flush",
+           "mi_rtj_pipe_profile", "mi_rtj_pipe_times"]
 
 
 KERNELS = ("k_index_summarize", "k_index_resolve", "k_index_emit", "k_decode", "k_spec_walk", "k_spec_verify")
@@ -83,6 +84,8 @@ def load():
                                    C.POINTER(C.c_uint64)]
     L.mi_rtj_pipe_peek_tag.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.mi_rtj_pipe_flush.argtypes = [vp]
+    L.mi_rtj_pipe_profile.argtypes = [vp, C.c_int]
+    L.mi_rtj_pipe_times.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.mi_rtj_plan_read_index.argtypes = [vp, u32p, C.c_size_t]
     L.mi_rtj_synth_frames.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, vp]
     L.mi_rtj_encode_bound.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
@@ -214,6 +217,17 @@ class Pipe:
 
     def flush(self):
         self.owner._chk(self.owner.L.mi_rtj_pipe_flush(self.h))
+
+    def profile(self, enable):
+        """kernel timing of the packets decoded from here on (flushes the session; not for timed regions)"""
+        self.owner._chk(self.owner.L.mi_rtj_pipe_profile(self.h, 1 if enable else 0))
+
+    def times(self):
+        """({kernel: ms summed over the packets decoded since profile(True)}, packets)"""
+        ms = (C.c_float * len(KERNELS))()
+        n = C.c_int()
+        self.owner._chk(self.owner.L.mi_rtj_pipe_times(self.h, ms, C.byref(n)))
+        return dict(zip(KERNELS, [float(x) for x in ms])), n.value
 
 
 class MiRtj:

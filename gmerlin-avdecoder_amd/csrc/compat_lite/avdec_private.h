@@ -51,7 +51,19 @@ typedef struct {
 } gavl_packet_t;
 typedef gavl_packet_t bgav_packet_t;
 
-typedef struct gavl_dictionary_s { char format[64]; } gavl_dictionary_t;
+/* a dictionary as far as this wrapper looks into one: the "Format" string it sets, and integer options it reads */
+#define MI_COMPAT_DICT_INTS 8
+typedef struct gavl_dictionary_s {
+  char format[64];
+  int n_ints;
+  struct { char key[32]; int val; } ints[MI_COMPAT_DICT_INTS];
+} gavl_dictionary_t;
+typedef gavl_dictionary_t bgav_options_t; /* "Options are now passed as dictionary", include/avdec.h:252-254 */
+
+/* gavl/compression.h */
+#define GAVL_COMPRESSION_HAS_P_FRAMES (1 << 0)
+#define GAVL_COMPRESSION_HAS_B_FRAMES (1 << 1)
+typedef struct { int flags; } gavl_compression_info_t;
 
 typedef struct bgav_stream_s bgav_stream_t;
 typedef struct bgav_video_decoder_s bgav_video_decoder_t;
@@ -66,6 +78,8 @@ struct bgav_stream_s {
   uint32_t fourcc;
   gavl_dictionary_t *m;    /* stream metadata */
   gavl_dictionary_t *info; /* what .probe receives */
+  const bgav_options_t *opt;   /* include/avdec_private.h:265; lib/video_v4l2_m2m.c:66 reads BGAV_OPT_VIDEOBUFFER from it */
+  gavl_compression_info_t *ci; /* include/avdec_private.h:358; lib/video.c:596 tests GAVL_COMPRESSION_HAS_P_FRAMES */
   struct { struct { gavl_video_format_t *format; } video; } data;
   /* harness side: the packet queue behind bgav_stream_get_packet_read */
   void *harness;
@@ -92,6 +106,7 @@ void bgav_stream_done_packet_read(bgav_stream_t *s, bgav_packet_t *p);
 void bgav_set_video_frame_from_packet(const bgav_packet_t *p, gavl_video_frame_t *f);
 void bgav_video_decoder_register(bgav_video_decoder_t *dec);
 void gavl_dictionary_set_string(gavl_dictionary_t *d, const char *key, const char *val);
+int gavl_dictionary_get_int(const gavl_dictionary_t *d, const char *key, int *val); /* 1 if the key is there */
 gavl_video_frame_t *gavl_video_frame_create(const gavl_video_format_t *format); /* NULL: no plane memory */
 void gavl_video_frame_null(gavl_video_frame_t *f);
 void gavl_video_frame_destroy(gavl_video_frame_t *f);

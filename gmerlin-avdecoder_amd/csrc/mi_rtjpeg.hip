@@ -96,6 +96,8 @@ struct mi_rtj_plan {
   uint32_t* d_spec_state = nullptr;        // [2]: launches in a row that refused every packet, launches left paused
   int rotate = -1;                         // MI_RTJ_ROTATE: 1 / 0 = a k_decode wave takes all three parts of its groups / one part; -1 = by batch size
   const uint8_t* prev_pic = nullptr;       // sessions: where unchanged blocks of this launch are copied from
+  hipStream_t idx_stream = nullptr;        // sessions: the stream of the index kernels (not owned); null = the instance's
+  hipEvent_t e_idx = nullptr;              // index done (only used with idx_stream)
   std::vector<Timed> ev[MI_RTJ_NUM_KERNELS];  // one pair per launch while profiling
   int launches = 0;
 };
@@ -111,6 +113,9 @@ struct PipeSlot {
   uint8_t* d_pic = nullptr;    // this packet's picture on the device (starts as a copy of its predecessor's)
   uint8_t* h_pic = nullptr;    // pinned host picture handed to the caller
   size_t pic_cap = 0;
+  bool owns_pic = true;        // false: d_pic / h_pic point into the session's group buffers (copies out in groups)
+  int out_state = 0;           // 0 nothing to copy, 1 decoded and waiting for its group's copy out, 2 copy out queued
+  hipEvent_t out_ev = nullptr; // the event that says this picture is in host memory (e_out of the slot that closed the copy)
   hipEvent_t e_in = nullptr, e_dec = nullptr, e_out = nullptr;
   uint64_t tag = 0;
   int w = 0, h = 0;
@@ -131,7 +136,23 @@ struct mi_rtj_pipe {
   int lent = -1;              // slot whose host picture the caller is looking at (until the next mi_rtj_pipe_next)
   const uint8_t* prev_pic = nullptr;  // device picture of the packet submitted last (what 0xFF blocks keep)
   size_t prev_bytes = 0;
-  hipStream_t s_in = nullptr, s_out = nullptr;  // kernels run on the instance's stream
+  // kernels run on the instance's stream; packets come in on s_in; pictures leave on s_out[slot & 1]: with one stream a
+  // session has one picture-sized copy out in flight at a time, and the link gives such a copy (3.1 MB at 1080p) 38 GB/s
+  // where two side by side, or larger ones, get past 50 (profiles/r02/pcie_probe.json); MI_RTJ_OUT_STREAMS=1 is the A/B
+  hipStream_t s_in = nullptr, s_out[2] = {nullptr, nullptr};
+  int n_out = 2;
+  // Pictures leave in groups: the slots of a group lie side by side on the device and in pinned host memory, and one
+  // copy takes all of them once the group's last packet is decoded (or as many as are decoded when the caller asks for
+  // one earlier).  The link moves a 1080p picture (3.1 MB) at 38 GB/s and 6-12 MB at 47-55 (profiles/r02/pcie_probe.json),
+  // and two copy streams do NOT overlap two small copies (profiles/r03/e2e_what_bounds_a_session.txt).
+  // MI_RTJ_OUT_GROUP = 1 / 2 / 4; sessions without a fixed coded size copy picture by picture.
+  int group = 1;
+  size_t grp_fsz = 0;                  // bytes of one picture in a group buffer
+  std::vector<uint8_t*> d_grp, h_grp;  // [depth / group]
+  hipStream_t s_idx = nullptr;         // MI_RTJ_IDX_STREAM=1 (A/B, slower): index kernels of the packets on a stream of their own
+  int out_kernel = 0;  // MI_RTJ_OUT_KERNEL=1: the picture leaves through a copy kernel that stores into the pinned host
+                       // picture, instead of the copy engine (A/B)
+  int exp_skip = 0;    // MI_RTJ_EXP_SKIP (experiments, wrong pictures): 1 no copy out, 2 no kernels, 4 no copy in
   uint64_t submitted = 0, returned = 0;
   // The thread that submits is what bounds a session (about 50 us of runtime calls per packet next to the 30 us it
   // takes to copy a 1080p packet into pinned staging), so the two halves run on two threads: the caller copies, a
@@ -334,6 +355,11 @@ int plan_upload(mi_rtj_plan* p) {
 int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
   mi_rtj_ctx* c = p->ctx;
   const uint8_t* st = (const uint8_t*)d_stream;
+  // The index kernels run on `is`, k_decode on the instance's stream.  Plans have them equal; a session gives its slots
+  // an index stream of their own (p->idx_stream), so that the index of packet i + 1 is built while packet i — whose
+  // picture the unchanged blocks of i + 1 come from — is still being transformed.
+  hipStream_t const ds = c->stream, is = p->idx_stream ? p->idx_stream : c->stream;
+  hipStream_t cur = is;
   Timed t[MI_RTJ_NUM_KERNELS];
   // while profiling: one event after every kernel; a kernel's start is its predecessor's end (they run back
   // to back on one stream), so a launch costs one event record per kernel instead of two
@@ -346,13 +372,13 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
       return MI_RTJ_OK;
     }
     HIPCHK(c, hipEventCreate(&t[k].a));
-    HIPCHK(c, hipEventRecord(t[k].a, c->stream));
+    HIPCHK(c, hipEventRecord(t[k].a, cur));
     return MI_RTJ_OK;
   };
   auto end = [&](int k) -> int {
     if (!p->profile) return MI_RTJ_OK;
     HIPCHK(c, hipEventCreate(&t[k].b));
-    HIPCHK(c, hipEventRecord(t[k].b, c->stream));
+    HIPCHK(c, hipEventRecord(t[k].b, cur));
     p->ev[k].push_back(t[k]);
     prev = t[k].b;
     return MI_RTJ_OK;
@@ -360,7 +386,7 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
   int rc;
   if (p->serial_index) {
     if ((rc = begin(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
-    hipLaunchKernelGGL(k_index_walk, dim3(p->n), dim3(64), 0, c->stream, p->d_frames, st, c->d_lut, p->d_blkoff);
+    hipLaunchKernelGGL(k_index_walk, dim3(p->n), dim3(64), 0, is, p->d_frames, st, c->d_lut, p->d_blkoff);
     if ((rc = end(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
   } else {
     const uint32_t *todo = nullptr, *ntodo = nullptr;
@@ -375,13 +401,13 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
       ntodo = p->d_spec_todo;
       todo = p->d_spec_todo + 1;
       rows = std::min<unsigned>(rows, kSpecFallbackRows);
-      HIPCHK(c, hipMemsetAsync(p->d_spec_todo, 0, sizeof(uint32_t), c->stream));
-      HIPCHK(c, hipMemsetAsync(p->d_spec_nfix, 0, sizeof(uint32_t), c->stream));
+      HIPCHK(c, hipMemsetAsync(p->d_spec_todo, 0, sizeof(uint32_t), is));
+      HIPCHK(c, hipMemsetAsync(p->d_spec_nfix, 0, sizeof(uint32_t), is));
       if ((rc = begin(MI_RTJ_K_SPEC_WALK)) != MI_RTJ_OK) return rc;
       // both walker forms (short and long lead) are queued; the one the policy state does not name returns at once
       const dim3 wgrid((unsigned)((p->n_spec + 63) / 64));
 #define MIRTJ_LAUNCH_WALK(PHASE, LEAD)                                                                                  \
-  hipLaunchKernelGGL((k_spec_walk<PHASE, LEAD>), wgrid, dim3(64), 0, c->stream, p->d_frames, p->d_spec_chunks,         \
+  hipLaunchKernelGGL((k_spec_walk<PHASE, LEAD>), wgrid, dim3(64), 0, is, p->d_frames, p->d_spec_chunks,         \
                      (uint32_t)p->n_spec, st, c->d_lut, p->d_spec_rec, p->d_spec_nrec, p->d_spec_wstart, p->d_spec_hand, \
                      state)
       if (p->one_block_type) {
@@ -396,46 +422,53 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
       if ((rc = begin(MI_RTJ_K_SPEC_VERIFY)) != MI_RTJ_OK) return rc;
       // first pass; walkers that had not fallen into step are walked again from a known block start; second
       // pass over the packets concerned (both return at once when there is nothing to repair)
-      hipLaunchKernelGGL(k_spec_verify, dim3(p->n), dim3(kSpecVerThreads), 0, c->stream, p->d_frames, p->d_spec_base, c->d_lut,
+      hipLaunchKernelGGL(k_spec_verify, dim3(p->n), dim3(kSpecVerThreads), 0, is, p->d_frames, p->d_spec_base, c->d_lut,
                          p->d_spec_rec, p->d_spec_nrec, p->d_blkoff, p->d_spec_ok, p->d_spec_todo + 1, p->d_spec_todo, state,
                          p->d_spec_wstart, p->d_spec_hand, p->d_spec_fix, p->d_spec_nfix, 1);
-      hipLaunchKernelGGL(k_spec_repair, dim3(kSpecRepairGrid), dim3(64), 0, c->stream, p->d_frames, p->d_spec_chunks, st,
+      hipLaunchKernelGGL(k_spec_repair, dim3(kSpecRepairGrid), dim3(64), 0, is, p->d_frames, p->d_spec_chunks, st,
                          c->d_lut, p->d_spec_rec, p->d_spec_nrec, p->d_spec_wstart, p->d_spec_hand, p->d_spec_fix, p->d_spec_nfix);
-      hipLaunchKernelGGL(k_spec_verify, dim3(p->n), dim3(kSpecVerThreads), 0, c->stream, p->d_frames, p->d_spec_base, c->d_lut,
+      hipLaunchKernelGGL(k_spec_verify, dim3(p->n), dim3(kSpecVerThreads), 0, is, p->d_frames, p->d_spec_base, c->d_lut,
                          p->d_spec_rec, p->d_spec_nrec, p->d_blkoff, p->d_spec_ok, p->d_spec_todo + 1, p->d_spec_todo, state,
                          p->d_spec_wstart, p->d_spec_hand, p->d_spec_fix, p->d_spec_nfix, 2);
       if ((rc = end(MI_RTJ_K_SPEC_VERIFY)) != MI_RTJ_OK) return rc;
-      if (state) hipLaunchKernelGGL(k_spec_policy, dim3(1), dim3(256), 0, c->stream, (uint32_t)p->n, (uint32_t)p->n_spec, p->d_spec_todo, p->d_spec_nfix, state);
+      if (state) hipLaunchKernelGGL(k_spec_policy, dim3(1), dim3(256), 0, is, (uint32_t)p->n, (uint32_t)p->n_spec, p->d_spec_todo, p->d_spec_nfix, state);
     }
     if ((rc = begin(MI_RTJ_K_SUMMARIZE)) != MI_RTJ_OK) return rc;
     if (todo) {
       if (p->one_block_type)
-        hipLaunchKernelGGL(k_index_summarize_todo<1>, dim3(p->max_chunks, rows), dim3(kSumThreads), 0, c->stream,
+        hipLaunchKernelGGL(k_index_summarize_todo<1>, dim3(p->max_chunks, rows), dim3(kSumThreads), 0, is,
                            p->d_frames, st, c->d_lut, p->d_summary, p->d_lentab, todo, ntodo);
       else
-        hipLaunchKernelGGL(k_index_summarize_todo<2>, dim3(p->max_chunks, rows), dim3(kSumThreads), 0, c->stream,
+        hipLaunchKernelGGL(k_index_summarize_todo<2>, dim3(p->max_chunks, rows), dim3(kSumThreads), 0, is,
                            p->d_frames, st, c->d_lut, p->d_summary, p->d_lentab, todo, ntodo);
     } else if (p->one_block_type) {
-      hipLaunchKernelGGL(k_index_summarize<1>, dim3(p->max_chunks, rows), dim3(kSumThreads), 0, c->stream, p->d_frames,
+      hipLaunchKernelGGL(k_index_summarize<1>, dim3(p->max_chunks, rows), dim3(kSumThreads), 0, is, p->d_frames,
                          st, c->d_lut, p->d_summary, p->d_lentab);
     } else {
-      hipLaunchKernelGGL(k_index_summarize<2>, dim3(p->max_chunks, rows), dim3(kSumThreads), 0, c->stream, p->d_frames,
+      hipLaunchKernelGGL(k_index_summarize<2>, dim3(p->max_chunks, rows), dim3(kSumThreads), 0, is, p->d_frames,
                          st, c->d_lut, p->d_summary, p->d_lentab);
     }
     if ((rc = end(MI_RTJ_K_SUMMARIZE)) != MI_RTJ_OK) return rc;
     if ((rc = begin(MI_RTJ_K_RESOLVE)) != MI_RTJ_OK) return rc;
-    hipLaunchKernelGGL(k_index_resolve, dim3(todo ? std::min<unsigned>((unsigned)p->n, 1024u) : rows), dim3(256), 0, c->stream, p->d_frames, p->d_summary,
+    hipLaunchKernelGGL(k_index_resolve, dim3(todo ? std::min<unsigned>((unsigned)p->n, 1024u) : rows), dim3(256), 0, is, p->d_frames, p->d_summary,
                        p->d_chunk_pos, p->d_chunk_mb, todo, ntodo);
     if ((rc = end(MI_RTJ_K_RESOLVE)) != MI_RTJ_OK) return rc;
     if ((rc = begin(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
     if (p->emit_walk)
-      hipLaunchKernelGGL(k_index_emit_walk, dim3(p->max_chunks, p->n), dim3(64), 0, c->stream, p->d_frames, st,
+      hipLaunchKernelGGL(k_index_emit_walk, dim3(p->max_chunks, p->n), dim3(64), 0, is, p->d_frames, st,
                          c->d_lut, p->d_chunk_pos, p->d_chunk_mb, p->d_blkoff);
     else
-      hipLaunchKernelGGL(k_index_emit, dim3(p->max_chunks, rows), dim3(kEmitThreads), 0, c->stream, p->d_frames,
+      hipLaunchKernelGGL(k_index_emit, dim3(p->max_chunks, rows), dim3(kEmitThreads), 0, is, p->d_frames,
                          p->d_lentab, p->d_chunk_pos, p->d_chunk_mb, p->d_blkoff, todo, ntodo);
     if ((rc = end(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
   }
+  if (is != ds) {  // k_decode waits for the index (and, through it, for the packet's copy in)
+    if (!p->e_idx) HIPCHK(c, hipEventCreateWithFlags(&p->e_idx, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(p->e_idx, is));
+    HIPCHK(c, hipStreamWaitEvent(ds, p->e_idx, 0));
+    prev = nullptr;  // (profiling) k_decode's start is not the end of a kernel on another stream
+  }
+  cur = ds;
   if ((rc = begin(MI_RTJ_K_DECODE)) != MI_RTJ_OK) return rc;
   // the A/B override is honoured only where it still covers every group
   // a wave per (slot, part) or, in batches that still make enough waves that way, per slot: the wave then takes the
@@ -452,17 +485,17 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
     // fetched from the previous packet's picture); a launch runs the one that carries nothing else
     if (span == 3u) {
       if (p->prev_pic)
-        hipLaunchKernelGGL((k_decode<true, true>), grid, block, 0, c->stream, p->d_frames, st, c->d_lut, p->d_blkoff, out8,
+        hipLaunchKernelGGL((k_decode<true, true>), grid, block, 0, ds, p->d_frames, st, c->d_lut, p->d_blkoff, out8,
                            p->prev_pic);
       else
-        hipLaunchKernelGGL((k_decode<true, false>), grid, block, 0, c->stream, p->d_frames, st, c->d_lut, p->d_blkoff, out8,
+        hipLaunchKernelGGL((k_decode<true, false>), grid, block, 0, ds, p->d_frames, st, c->d_lut, p->d_blkoff, out8,
                            (const uint8_t*)nullptr);
     } else {
       if (p->prev_pic)
-        hipLaunchKernelGGL((k_decode<false, true>), grid, block, 0, c->stream, p->d_frames, st, c->d_lut, p->d_blkoff, out8,
+        hipLaunchKernelGGL((k_decode<false, true>), grid, block, 0, ds, p->d_frames, st, c->d_lut, p->d_blkoff, out8,
                            p->prev_pic);
       else
-        hipLaunchKernelGGL((k_decode<false, false>), grid, block, 0, c->stream, p->d_frames, st, c->d_lut, p->d_blkoff,
+        hipLaunchKernelGGL((k_decode<false, false>), grid, block, 0, ds, p->d_frames, st, c->d_lut, p->d_blkoff,
                            out8, (const uint8_t*)nullptr);
     }
   }
@@ -705,6 +738,7 @@ void mi_rtj_plan_destroy(mi_rtj_plan* p) {
   if (p->d_spec_todo) (void)hipFree(p->d_spec_todo);
   if (p->d_spec_state) (void)hipFree(p->d_spec_state);
   if (p->d_spec_ok) (void)hipFree(p->d_spec_ok);
+  if (p->e_idx) (void)hipEventDestroy(p->e_idx);
   delete p;
 }
 
@@ -950,26 +984,65 @@ int mi_rtj_decode_nocopy(mi_rtj_ctx* c, const uint8_t* pkt, size_t len, const ui
 namespace {
 // everything of one packet that goes to the device: copy in, kernels, copy out (called on the worker thread, or on
 // the caller's when the session runs without one)
+// how the pinned host pictures are allocated (MI_RTJ_HOST_FLAGS, experiments: 1 non-coherent, 2 coherent, 4 write-combined)
+unsigned pic_host_flags() {
+  const char* f = getenv("MI_RTJ_HOST_FLAGS");
+  const int v = f ? atoi(f) : 0;
+  unsigned fl = hipHostMallocDefault;
+  if (v & 1) fl |= hipHostMallocNonCoherent;
+  if (v & 2) fl |= hipHostMallocCoherent;
+  if (v & 4) fl |= hipHostMallocWriteCombined;
+  return fl;
+}
+
+// queue the copy out of slot `last` together with the decoded, not yet copied slots of its group right before it
+int pipe_copy_out(mi_rtj_pipe* q, int last) {
+  mi_rtj_ctx* c = q->ctx;
+  int first = last;
+  while (first % q->group != 0 && q->slot[first - 1].out_state == 1 && q->slot[first - 1].w == q->slot[last].w &&
+         q->slot[first - 1].h == q->slot[last].h)
+    first--;
+  PipeSlot& a = q->slot[first];
+  PipeSlot& z = q->slot[last];
+  const size_t fsz = (size_t)z.w * z.h * 3 / 2;
+  const size_t bytes = (size_t)(z.d_pic - a.d_pic) + fsz;  // one slot: fsz; a group: its members lie side by side
+  hipStream_t so = q->s_out[(last / q->group) % q->n_out];
+  HIPCHK(c, hipStreamWaitEvent(so, z.e_dec, 0));  // the kernels of the earlier members ran before it, on the same stream
+  if (q->exp_skip & 1) {
+  } else if (q->out_kernel) {
+    hipLaunchKernelGGL(k_copy16, dim3(q->out_kernel), dim3(256), 0, so, (const uint4*)a.d_pic, (uint4*)a.h_pic, bytes / 16);
+  } else {
+    HIPCHK(c, hipMemcpyAsync(a.h_pic, a.d_pic, bytes, hipMemcpyDeviceToHost, so));
+  }
+  HIPCHK(c, hipEventRecord(z.e_out, so));
+  for (int i = first; i <= last; i++) {
+    q->slot[i].out_state = 2;
+    q->slot[i].out_ev = z.e_out;
+  }
+  return MI_RTJ_OK;
+}
+
 int pipe_issue(mi_rtj_pipe* q, PipeSlot& sl) {
   mi_rtj_ctx* c = q->ctx;
   mi_rtj_plan* p = sl.plan;
-  const size_t fsz = (size_t)sl.w * sl.h * 3 / 2;
   // (the copy in has a stream of its own: queued between the kernels of successive packets the session ran at
   // 6-10 K pictures per second instead of 12 K, and the deeper the pipeline the slower — profiles/r02/e2e_*.txt)
-  HIPCHK(c, hipMemcpyAsync(sl.d_stage, sl.h_stage, sizeof(FrameDev) + sl.len, hipMemcpyHostToDevice, q->s_in));
+  if (!(q->exp_skip & 4))
+    HIPCHK(c, hipMemcpyAsync(sl.d_stage, sl.h_stage, sizeof(FrameDev) + sl.len, hipMemcpyHostToDevice, q->s_in));
   HIPCHK(c, hipEventRecord(sl.e_in, q->s_in));
-  HIPCHK(c, hipStreamWaitEvent(c->stream, sl.e_in, 0));
+  HIPCHK(c, hipStreamWaitEvent(p->idx_stream ? p->idx_stream : c->stream, sl.e_in, 0));
   // kernels, in submission order on the instance's stream.  Unchanged (0xFF) blocks: k_decode fetches them from the
   // predecessor's picture (a packet of another size has no predecessor in that sense: its unchanged blocks keep what
   // the slot's buffer holds, zeros at first)
   p->prev_pic = sl.prev;
-  const int rc = plan_launch(p, sl.d_stage, sl.d_pic);
+  const int rc = (q->exp_skip & 2) ? MI_RTJ_OK : plan_launch(p, sl.d_stage, sl.d_pic);
   if (rc != MI_RTJ_OK) return rc;
   HIPCHK(c, hipEventRecord(sl.e_dec, c->stream));
-  // copy out, on the third stream
-  HIPCHK(c, hipStreamWaitEvent(q->s_out, sl.e_dec, 0));
-  HIPCHK(c, hipMemcpyAsync(sl.h_pic, sl.d_pic, fsz, hipMemcpyDeviceToHost, q->s_out));
-  HIPCHK(c, hipEventRecord(sl.e_out, q->s_out));
+  // copy out: queued now if this packet closes its group, else when the group's last packet is decoded or the caller
+  // asks for one of its pictures, whichever comes first
+  sl.out_state = 1;
+  const int idx = (int)(&sl - q->slot.data());
+  if (idx % q->group == q->group - 1) return pipe_copy_out(q, idx);
   return MI_RTJ_OK;
 }
 
@@ -1020,8 +1093,35 @@ mi_rtj_pipe* mi_rtj_pipe_create(mi_rtj_ctx* c, int depth, int max_w, int max_h) 
   q->max_w = max_w;
   q->max_h = max_h;
   q->slot.resize(depth);
-  bool ok = hipStreamCreateWithFlags(&q->s_in, hipStreamNonBlocking) == hipSuccess &&
-            hipStreamCreateWithFlags(&q->s_out, hipStreamNonBlocking) == hipSuccess;
+  {
+    const char* os = getenv("MI_RTJ_OUT_STREAMS");
+    q->n_out = os && atoi(os) == 1 ? 1 : 2;
+    const char* ok_ = getenv("MI_RTJ_OUT_KERNEL");
+    q->out_kernel = ok_ ? atoi(ok_) : 0;  // the value is the copy kernel's grid (workgroups of 256)
+    const char* sk = getenv("MI_RTJ_EXP_SKIP");
+    q->exp_skip = sk ? atoi(sk) : 0;
+  }
+  {
+    const char* og = getenv("MI_RTJ_OUT_GROUP");
+    const int g = og ? atoi(og) : 2;
+    // (groups need every picture to have the session's size, and the caller's thread to be the one that queues copies)
+    const char* th0 = getenv("MI_RTJ_PIPE_THREAD");
+    q->group = (max_w > 0 && max_h > 0 && !(th0 && atoi(th0) != 0) && (g == 2 || g == 4)) ? g : 1;
+    if (q->group > 1) {
+      q->depth = depth = (depth + q->group - 1) / q->group * q->group;
+      q->slot.resize(depth);
+      q->grp_fsz = (size_t)max_w * max_h * 3 / 2;
+    }
+  }
+  bool ok = hipStreamCreateWithFlags(&q->s_in, hipStreamNonBlocking) == hipSuccess;
+  {
+    // off unless asked for: with the index on a stream of its own a 1080p session ran at 6,600 pictures per second
+    // instead of 12,000 (profiles/r03/e2e_ab.txt) — every packet then crosses streams twice more, and the runtime's
+    // cross-stream waits cost more than the overlap of one packet's index with its predecessor's transform gives
+    const char* ix = getenv("MI_RTJ_IDX_STREAM");
+    if (ix && atoi(ix) != 0) ok = ok && hipStreamCreateWithFlags(&q->s_idx, hipStreamNonBlocking) == hipSuccess;
+  }
+  for (int i = 0; i < q->n_out; i++) ok = ok && hipStreamCreateWithFlags(&q->s_out[i], hipStreamNonBlocking) == hipSuccess;
   const char* mode = getenv("MI_RTJ_INDEX");
   const char* em = getenv("MI_RTJ_EMIT");
   for (auto& sl : q->slot) {
@@ -1032,12 +1132,31 @@ mi_rtj_pipe* mi_rtj_pipe_create(mi_rtj_ctx* c, int depth, int max_w, int max_h) 
     sl.plan->serial_index = mode && strcmp(mode, "serial") == 0;
     sl.plan->emit_walk = em && strcmp(em, "walk") == 0;
     sl.plan->h_frames.resize(1);
+    sl.plan->idx_stream = q->s_idx;
     ok = ok && hipEventCreateWithFlags(&sl.e_in, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&sl.e_dec, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&sl.e_out, hipEventDisableTiming) == hipSuccess;
   }
+  if (ok && q->group > 1) {  // the group buffers: `group` pictures side by side, on the device and in pinned host memory
+    const int ng = depth / q->group;
+    q->d_grp.assign(ng, nullptr);
+    q->h_grp.assign(ng, nullptr);
+    const size_t gb = q->grp_fsz * (size_t)q->group;
+    for (int g = 0; g < ng && ok; g++) {
+      ok = hipMalloc((void**)&q->d_grp[g], gb + kAllocPad) == hipSuccess &&
+           hipMemsetAsync(q->d_grp[g], 0, gb + kAllocPad, c->stream) == hipSuccess &&
+           hipHostMalloc((void**)&q->h_grp[g], gb, pic_host_flags()) == hipSuccess;
+      for (int j = 0; j < q->group && ok; j++) {
+        PipeSlot& sl = q->slot[g * q->group + j];
+        sl.d_pic = q->d_grp[g] + (size_t)j * q->grp_fsz;
+        sl.h_pic = q->h_grp[g] + (size_t)j * q->grp_fsz;
+        sl.pic_cap = q->grp_fsz;
+        sl.owns_pic = false;
+      }
+    }
+  }
   if (!ok) {
-    fail(c, MI_RTJ_ERR_HIP, "mi_rtj_pipe_create: cannot create streams / events");
+    fail(c, MI_RTJ_ERR_HIP, "mi_rtj_pipe_create: cannot create streams / events / picture buffers");
     mi_rtj_pipe_destroy(q);
     return nullptr;
   }
@@ -1065,8 +1184,10 @@ void mi_rtj_pipe_destroy(mi_rtj_pipe* q) {
     q->worker.join();  // it queues what it still holds, then leaves
   }
   if (q->s_in) (void)hipStreamSynchronize(q->s_in);
+  if (q->s_idx) (void)hipStreamSynchronize(q->s_idx);
   (void)hipStreamSynchronize(c->stream);
-  if (q->s_out) (void)hipStreamSynchronize(q->s_out);
+  for (hipStream_t so : q->s_out)
+    if (so) (void)hipStreamSynchronize(so);
   for (auto& sl : q->slot) {
     if (sl.plan) {
       sl.plan->d_frames = nullptr;  // points into d_stage, not owned by the plan
@@ -1074,14 +1195,23 @@ void mi_rtj_pipe_destroy(mi_rtj_pipe* q) {
     }
     if (sl.h_stage) (void)hipHostFree(sl.h_stage);
     if (sl.d_stage) (void)hipFree(sl.d_stage);
-    if (sl.d_pic) (void)hipFree(sl.d_pic);
-    if (sl.h_pic) (void)hipHostFree(sl.h_pic);
+    if (sl.owns_pic && sl.d_pic) (void)hipFree(sl.d_pic);
+    if (sl.owns_pic && sl.h_pic) (void)hipHostFree(sl.h_pic);
     if (sl.e_in) (void)hipEventDestroy(sl.e_in);
     if (sl.e_dec) (void)hipEventDestroy(sl.e_dec);
     if (sl.e_out) (void)hipEventDestroy(sl.e_out);
   }
+  for (uint8_t* g : q->d_grp)
+    if (g) (void)hipFree(g);
+  for (uint8_t* g : q->h_grp)
+    if (g) (void)hipHostFree(g);
   if (q->s_in) (void)hipStreamDestroy(q->s_in);
-  if (q->s_out) (void)hipStreamDestroy(q->s_out);
+  if (q->s_idx) {
+    (void)hipStreamSynchronize(q->s_idx);
+    (void)hipStreamDestroy(q->s_idx);
+  }
+  for (hipStream_t so : q->s_out)
+    if (so) (void)hipStreamDestroy(so);
   delete q;
 }
 
@@ -1095,6 +1225,9 @@ int mi_rtj_pipe_pending(const mi_rtj_pipe* q) { return q ? q->count : 0; }
 int mi_rtj_pipe_submit(mi_rtj_pipe* q, const uint8_t* pkt, size_t len, uint64_t tag) {
   if (!q || !pkt) return fail(q ? q->ctx : nullptr, MI_RTJ_ERR_ARG, "mi_rtj_pipe_submit: NULL argument");
   mi_rtj_ctx* c = q->ctx;
+  // (an error message is written into the instance, which the worker thread of a threaded session writes too: the
+  // worker is idle before any of the refusals below speaks — ADVICE r2)
+  if (len < MI_RTJ_HEADER_SIZE || mi_rtj_pipe_room(q) <= 0) pipe_drain_jobs(q);
   if (len < MI_RTJ_HEADER_SIZE) return fail(c, MI_RTJ_ERR_ARG, "mi_rtj_pipe_submit: packet shorter than its %d-byte header", MI_RTJ_HEADER_SIZE);
   if (mi_rtj_pipe_room(q) <= 0) return fail(c, MI_RTJ_ERR_ARG, "mi_rtj_pipe_submit: %d packets in flight already (take a picture first)", q->count);
   HIPCHK(c, hipSetDevice(c->device));
@@ -1102,6 +1235,7 @@ int mi_rtj_pipe_submit(mi_rtj_pipe* q, const uint8_t* pkt, size_t len, uint64_t 
   // gigabytes; the reference's frame has the container's size whatever the packet says, lib/video_rtjpeg.c:50-54)
   {
     const int hw = pkt[6] | (pkt[7] << 8), hh = pkt[8] | (pkt[9] << 8);
+    if (q->max_w && q->max_h && (hw != q->max_w || hh != q->max_h)) pipe_drain_jobs(q);
     if (q->max_w && q->max_h && (hw != q->max_w || hh != q->max_h))
       return fail(c, MI_RTJ_ERR_GEOMETRY, "packet header %dx%d does not match the stream's coded size %dx%d", hw, hh, q->max_w, q->max_h);
   }
@@ -1128,6 +1262,8 @@ int mi_rtj_pipe_submit(mi_rtj_pipe* q, const uint8_t* pkt, size_t len, uint64_t 
   if (rc != MI_RTJ_OK) return rc;
   p->h_frames[0] = f;
   const size_t fsz = (size_t)f.w * f.h * 3 / 2;
+  if (fsz > sl.pic_cap && !sl.owns_pic)  // cannot happen: grouped sessions refuse packets of another size above
+    return fail(c, MI_RTJ_ERR_GEOMETRY, "mi_rtj_pipe_submit: picture larger than the session's");
   if (fsz > sl.pic_cap) {
     if (sl.d_pic) (void)hipFree(sl.d_pic);
     if (sl.h_pic) (void)hipHostFree(sl.h_pic);
@@ -1135,7 +1271,7 @@ int mi_rtj_pipe_submit(mi_rtj_pipe* q, const uint8_t* pkt, size_t len, uint64_t 
     sl.pic_cap = 0;
     HIPCHK(c, hipMalloc((void**)&sl.d_pic, fsz + kAllocPad));
     HIPCHK(c, hipMemsetAsync(sl.d_pic, 0, fsz + kAllocPad, c->stream));
-    HIPCHK(c, hipHostMalloc((void**)&sl.h_pic, fsz, hipHostMallocDefault));
+    HIPCHK(c, hipHostMalloc((void**)&sl.h_pic, fsz, pic_host_flags()));
     sl.pic_cap = fsz;
   }
   const size_t need = sizeof(FrameDev) + len + kAllocPad;
@@ -1172,6 +1308,8 @@ int mi_rtj_pipe_submit(mi_rtj_pipe* q, const uint8_t* pkt, size_t len, uint64_t 
   sl.tag = tag;
   sl.w = (int)fd.w;
   sl.h = (int)fd.h;
+  const uint8_t* const was_prev = q->prev_pic;
+  const size_t was_bytes = q->prev_bytes;
   sl.prev = q->prev_pic && q->prev_bytes == fsz && q->prev_pic != sl.d_pic ? q->prev_pic : nullptr;
   q->prev_pic = sl.d_pic;
   q->prev_bytes = fsz;
@@ -1180,9 +1318,11 @@ int mi_rtj_pipe_submit(mi_rtj_pipe* q, const uint8_t* pkt, size_t len, uint64_t 
   if (!q->threaded) {
     sl.rc = pipe_issue(q, sl);
     sl.issued = 1;
-    if (sl.rc != MI_RTJ_OK) {  // undo: the packet never went in
+    if (sl.rc != MI_RTJ_OK) {  // undo: the packet never went in, its predecessor is still the last picture
       q->count--;
       q->submitted--;
+      q->prev_pic = was_prev;
+      q->prev_bytes = was_bytes;
       return sl.rc;
     }
     return MI_RTJ_OK;
@@ -1216,7 +1356,14 @@ int mi_rtj_pipe_next(mi_rtj_pipe* q, const uint8_t* planes[3], int strides[3], i
     q->count--;
     return rc;
   }
-  HIPCHK(c, hipEventSynchronize(sl.e_out));
+  if (sl.out_state == 1) {  // its group is not complete yet: the copy goes out now, with what is decoded behind it
+    int last = q->head;
+    while ((last + 1) % q->group != 0 && last + 1 < q->depth && q->slot[last + 1].out_state == 1) last++;
+    const int rc = pipe_copy_out(q, last);
+    if (rc != MI_RTJ_OK) return rc;
+  }
+  HIPCHK(c, hipEventSynchronize(sl.out_ev ? sl.out_ev : sl.e_out));
+  sl.out_state = 0;
   if (planes) {
     const size_t ysz = (size_t)sl.w * sl.h;
     planes[0] = sl.h_pic;
@@ -1237,6 +1384,33 @@ int mi_rtj_pipe_next(mi_rtj_pipe* q, const uint8_t* planes[3], int strides[3], i
   return MI_RTJ_OK;
 }
 
+// Kernel times of a session (bench.py's roofline for the in-order workloads): profiling records two events per kernel
+// and packet on the submitting thread, so it is switched on for a lap of its own, never inside a timed region.
+int mi_rtj_pipe_profile(mi_rtj_pipe* q, int enable) {
+  if (!q) return MI_RTJ_ERR_ARG;
+  const int rc = mi_rtj_pipe_flush(q);
+  if (rc != MI_RTJ_OK) return rc;
+  for (auto& sl : q->slot) mi_rtj_plan_profile(sl.plan, enable);
+  return MI_RTJ_OK;
+}
+
+int mi_rtj_pipe_times(mi_rtj_pipe* q, float ms[MI_RTJ_NUM_KERNELS], int* launches) {
+  if (!q || !ms) return MI_RTJ_ERR_ARG;
+  pipe_drain_jobs(q);
+  int total = 0;
+  for (int k = 0; k < MI_RTJ_NUM_KERNELS; k++) ms[k] = 0.f;
+  for (auto& sl : q->slot) {
+    float one[MI_RTJ_NUM_KERNELS];
+    int n = 0;
+    const int rc = mi_rtj_plan_times(sl.plan, one, &n);
+    if (rc != MI_RTJ_OK) return rc;
+    for (int k = 0; k < MI_RTJ_NUM_KERNELS; k++) ms[k] += one[k];
+    total += n;
+  }
+  if (launches) *launches = total;
+  return MI_RTJ_OK;
+}
+
 int mi_rtj_pipe_peek_tag(const mi_rtj_pipe* q, uint64_t* tag) {
   if (!q || !tag || q->count == 0) return MI_RTJ_ERR_ARG;
   *tag = q->slot[q->head].tag;
@@ -1251,7 +1425,9 @@ int mi_rtj_pipe_flush(mi_rtj_pipe* q) {
   pipe_drain_jobs(q);
   HIPCHK(c, hipStreamSynchronize(q->s_in));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipStreamSynchronize(q->s_out));
+  if (q->s_idx) HIPCHK(c, hipStreamSynchronize(q->s_idx));
+  for (int i = 0; i < q->n_out; i++) HIPCHK(c, hipStreamSynchronize(q->s_out[i]));
+  for (auto& sl : q->slot) sl.out_state = 0;
   q->head = (q->head + q->count) % q->depth;
   q->count = 0;
   q->lent = -1;

@@ -10,6 +10,18 @@
  *
  * Host code stays C.  Build inside the tree with the real <avdec_private.h>; the compat_lite/
  * headers next to this file exist only so that the test harness can compile it without gavl.
+ *
+ * Three flavours, one file:
+ *   (no flag)            the read-ahead, frame-owning decoder: packets in flight on the device, pictures handed out in
+ *                        the instance's pinned host memory (s->vframe, lib/video.c:420-441), .resync and .skipto.  This is
+ *                        what a maintainer gets by default and the fastest by far (end to end).
+ *   -DMI_RTJ_SYNC_NOCOPY synchronous and frame-owning: one packet in, one picture out per call.
+ *   -DMI_RTJ_COPY_MODE   synchronous into the caller's frame, honouring its strides — lib/video_rtjpeg.c's own shape.
+ * (-DMI_RTJ_PIPELINE / -DMI_RTJ_NOCOPY, round 2's spellings, still select the first two.)
+ *
+ * Options (the stream's options dictionary first, s->opt as lib/video_v4l2_m2m.c:66 reads BGAV_OPT_VIDEOBUFFER from it;
+ * the environment as fallback): "mi355x-device" / MI_RTJ_DEVICE = HIP device ordinal, "mi355x-depth" / MI_RTJ_DEPTH =
+ * packets in flight (2..64, default 6).
  */
 #include <stdlib.h>
 #include <string.h>
@@ -21,8 +33,8 @@
 
 #define LOG_DOMAIN "video_rtjpeg_mi355x"
 
-/* bgav_stream_t::out_time (include/avdec_private.h) tells a read-ahead decoder which pictures became stale when the
- * library skipped packets by itself; -DMI_RTJ_NO_OUT_TIME for a tree whose stream struct lacks it */
+/* .skipto leaves the time of the picture it stopped at in bgav_stream_t::out_time, as the library's own loop does
+ * (lib/video.c:636-655); -DMI_RTJ_NO_OUT_TIME for a tree whose stream struct lacks the member */
 #if !defined(MI_RTJ_NO_OUT_TIME) && !defined(MI_RTJ_HAVE_OUT_TIME)
 #define MI_RTJ_HAVE_OUT_TIME 1
 #endif
@@ -30,12 +42,29 @@
 #define BLOCK_SIZE 16
 #define PADD(x) ((((x) + BLOCK_SIZE - 1) / BLOCK_SIZE) * BLOCK_SIZE)
 
-#ifdef MI_RTJ_PIPELINE /* the read-ahead decoder is a frame-owning one */
+#if defined(MI_RTJ_COPY_MODE)
+#undef MI_RTJ_PIPELINE
+#undef MI_RTJ_NOCOPY
+#elif defined(MI_RTJ_SYNC_NOCOPY) || (defined(MI_RTJ_NOCOPY) && !defined(MI_RTJ_PIPELINE))
+#undef MI_RTJ_PIPELINE
 #ifndef MI_RTJ_NOCOPY
 #define MI_RTJ_NOCOPY 1
 #endif
-#define MI_RTJ_MAX_DEPTH 64
+#else /* the default: read ahead, own the frame */
+#ifndef MI_RTJ_PIPELINE
+#define MI_RTJ_PIPELINE 1
 #endif
+#ifndef MI_RTJ_NOCOPY
+#define MI_RTJ_NOCOPY 1
+#endif
+#endif
+#ifdef MI_RTJ_PIPELINE
+#define MI_RTJ_MAX_DEPTH 64
+#define MI_RTJ_DEFAULT_DEPTH 6
+#endif
+
+#define MI_RTJ_OPT_DEVICE "mi355x-device" /* int: HIP device ordinal */
+#define MI_RTJ_OPT_DEPTH "mi355x-depth"   /* int: packets in flight */
 
 typedef struct {
   mi_rtj_ctx *ctx; /* owns the persistent device picture: the role of priv->frame + priv->rtjpeg */
@@ -44,12 +73,28 @@ typedef struct {
 #endif
 #ifdef MI_RTJ_PIPELINE
   mi_rtj_pipe *pipe;                      /* packets in flight (include/mi_rtjpeg.h, "pipelined session") */
-  bgav_packet_t meta[MI_RTJ_MAX_DEPTH];   /* pts, duration, timecode... of the packets in flight, by tag % depth */
+  bgav_packet_t meta[MI_RTJ_MAX_DEPTH];   /* pts, duration, timecode... of the packets in flight, by tag % MI_RTJ_MAX_DEPTH
+                                           * (a session never has more in flight, whatever it rounds the depth to) */
   uint64_t next_tag;
   int depth;
   int eof;                                /* the packet source ran dry: hand out what is in flight, then EOF */
+  int have_last;                          /* last_end is valid */
+  int64_t last_end;                       /* pts + duration of the packet read last: where the next one should begin */
+  uint64_t gap_tag;                       /* first packet read after a gap in the time stamps (packets skipped at the
+                                           * source): everything in flight before it is stale */
+  int have_gap;
 #endif
 } rtjpeg_hip_priv_t;
+
+/* an integer option: the stream's options dictionary first (include/avdec_private.h:265, filled from bgav_options_t,
+ * include/avdec.h:258-267), then the environment, then the default */
+static int option_int(const bgav_stream_t *s, const char *key, const char *env, int dflt) {
+  int v;
+  const char *e;
+  if (s->opt && gavl_dictionary_get_int(s->opt, key, &v)) return v;
+  e = getenv(env);
+  return e ? atoi(e) : dflt;
+}
 
 /* .probe (include/avdec_private.h:95): claim the stream only if a gfx950 device is usable, so
  * that a CPU decoder registered after this one still gets it otherwise (first match wins,
@@ -61,9 +106,8 @@ static int probe_rtjpeg_hip(const gavl_dictionary_t *stream) {
 
 static int init_rtjpeg_hip(bgav_stream_t *s) {
   rtjpeg_hip_priv_t *priv = calloc(1, sizeof(*priv));
-  const char *dev = getenv("MI_RTJ_DEVICE"); /* default: the process's current device */
   if (!priv) return 0;
-  priv->ctx = mi_rtj_create(dev ? atoi(dev) : -1);
+  priv->ctx = mi_rtj_create(option_int(s, MI_RTJ_OPT_DEVICE, "MI_RTJ_DEVICE", -1)); /* -1: the process's current device */
   if (!priv->ctx) {
     gavl_log(GAVL_LOG_ERROR, LOG_DOMAIN, "Cannot open MI355X decoder: %s", mi_rtj_last_error(NULL));
     free(priv);
@@ -84,10 +128,7 @@ static int init_rtjpeg_hip(bgav_stream_t *s) {
 #endif
 #ifdef MI_RTJ_PIPELINE
   {
-    /* packets in flight: MI_RTJ_DEPTH (default 4: 12.0 K pictures per second at 1080p, 11.6 K with 6, 11.2 K with 8; BGAV_OPT_VIDEOBUFFER is what lib/video_v4l2_m2m.c:66 reads for
-     * the same purpose — an instance built inside the tree can take it from s->opt instead) */
-    const char *d = getenv("MI_RTJ_DEPTH");
-    priv->depth = d ? atoi(d) : 4;
+    priv->depth = option_int(s, MI_RTJ_OPT_DEPTH, "MI_RTJ_DEPTH", MI_RTJ_DEFAULT_DEPTH);
     if (priv->depth < 2) priv->depth = 2;
     if (priv->depth > MI_RTJ_MAX_DEPTH) priv->depth = MI_RTJ_MAX_DEPTH;
     priv->pipe = mi_rtj_pipe_create(priv->ctx, priv->depth, s->data.video.format->frame_width,
@@ -102,6 +143,11 @@ static int init_rtjpeg_hip(bgav_stream_t *s) {
       s->decoder_priv = NULL;
       return 0;
     }
+    /* A decoder that reads ahead cannot let the library skip packets behind its back (bgav_video_skipto's intra-only
+     * branch, lib/video.c:596-612, does not say where it skipped to, and the target may lie inside what is in flight),
+     * and a stream with unchanged (0xFF) blocks is not intra-only anyway: every packet has to pass through the decoder.
+     * With this flag the library calls .skipto with the exact target instead (lib/video.c:614-634). */
+    if (s->ci) s->ci->flags |= GAVL_COMPRESSION_HAS_P_FRAMES;
   }
 #endif
   return 1;
@@ -121,8 +167,17 @@ static gavl_source_status_t fill_pipeline(bgav_stream_t *s) {
       if (st == GAVL_SOURCE_EOF) priv->eof = 1;
       break;
     }
-    priv->meta[priv->next_tag % (uint64_t)priv->depth] = *p;
-    priv->meta[priv->next_tag % (uint64_t)priv->depth].buf.buf = NULL; /* the bytes are not ours to keep */
+    priv->meta[priv->next_tag % MI_RTJ_MAX_DEPTH] = *p;
+    priv->meta[priv->next_tag % MI_RTJ_MAX_DEPTH].buf.buf = NULL; /* the bytes are not ours to keep */
+    /* time stamps that jump forward: somebody skipped packets at the source (see decode_rtjpeg_pipe) */
+    if (priv->have_last && p->duration > 0 && p->pts > priv->last_end) {
+      priv->gap_tag = priv->next_tag;
+      priv->have_gap = 1;
+    }
+    if (p->duration > 0) {
+      priv->last_end = p->pts + p->duration;
+      priv->have_last = 1;
+    }
     if (mi_rtj_pipe_submit(priv->pipe, p->buf.buf, (size_t)p->buf.len, priv->next_tag) != MI_RTJ_OK) {
       gavl_log(GAVL_LOG_ERROR, LOG_DOMAIN, "Decoding failed: %s", mi_rtj_last_error(priv->ctx));
       bgav_stream_done_packet_read(s, p);
@@ -143,19 +198,27 @@ static gavl_source_status_t decode_rtjpeg_pipe(bgav_stream_t *s, gavl_video_fram
   gavl_source_status_t st;
   (void)f; /* always NULL for a frame-owning decoder (lib/video.c:262) */
   for (;;) {
+    /* Should the library skip packets at the source all the same (its intra-only branch; init asks it not to), what
+     * is in flight ends before the skip's target and is stale.  Two things prove that packets were skipped behind us:
+     * s->out_time (set to the first packet kept, lib/video.c:607) lies past the end of the last packet read here — then
+     * everything in flight goes —, or the time stamps of the packets read jump — then everything before the jump goes.
+     * Without either nothing was skipped at the source and nothing is dropped: round 2's rule (drop what ends before
+     * s->out_time) threw away pictures the caller was still waiting for when the target lay inside the read-ahead
+     * window, where out_time is just the start of the next unread packet. */
+#ifdef MI_RTJ_HAVE_OUT_TIME
+    while (priv->have_last && s->out_time != GAVL_TIME_UNDEFINED && s->out_time > priv->last_end &&
+           mi_rtj_pipe_peek_tag(priv->pipe, &tag) == MI_RTJ_OK)
+      mi_rtj_pipe_next(priv->pipe, NULL, NULL, NULL, NULL, NULL);
+#endif
     st = fill_pipeline(s);
     if (mi_rtj_pipe_pending(priv->pipe) == 0) return st == GAVL_SOURCE_OK ? GAVL_SOURCE_EOF : st; /* EOF or AGAIN */
-#ifdef MI_RTJ_HAVE_OUT_TIME
-    /* the library skips packets of intra-only streams by itself (bgav_video_skipto, lib/video.c:596-612) and sets
-     * s->out_time to the first packet it kept: pictures of packets read ahead before that are stale */
-    if (mi_rtj_pipe_peek_tag(priv->pipe, &tag) == MI_RTJ_OK) {
-      const bgav_packet_t *m = &priv->meta[tag % (uint64_t)priv->depth];
-      if (s->out_time != GAVL_TIME_UNDEFINED && m->duration > 0 && m->pts + m->duration <= s->out_time) {
+    if (priv->have_gap && mi_rtj_pipe_peek_tag(priv->pipe, &tag) == MI_RTJ_OK) {
+      if (tag < priv->gap_tag) {
         mi_rtj_pipe_next(priv->pipe, NULL, NULL, NULL, NULL, NULL);
         continue;
       }
+      priv->have_gap = 0;
     }
-#endif
     break;
   }
   if (mi_rtj_pipe_next(priv->pipe, planes, strides, NULL, NULL, &tag) != MI_RTJ_OK) {
@@ -166,7 +229,7 @@ static gavl_source_status_t decode_rtjpeg_pipe(bgav_stream_t *s, gavl_video_fram
     priv->vframe->planes[i] = (uint8_t *)planes[i];
     priv->vframe->strides[i] = strides[i];
   }
-  bgav_set_video_frame_from_packet(&priv->meta[tag % (uint64_t)priv->depth], priv->vframe);
+  bgav_set_video_frame_from_packet(&priv->meta[tag % MI_RTJ_MAX_DEPTH], priv->vframe);
   fill_pipeline(s); /* keep the device busy while the application looks at this picture */
   return GAVL_SOURCE_OK;
 }
@@ -177,6 +240,8 @@ static void resync_rtjpeg_pipe(bgav_stream_t *s) {
   rtjpeg_hip_priv_t *priv = s->decoder_priv;
   mi_rtj_pipe_flush(priv->pipe);
   priv->eof = 0;
+  priv->have_last = 0; /* the next packet's time stamp is a new beginning, not a gap */
+  priv->have_gap = 0;
 }
 
 /* .skipto (include/avdec_private.h:112-115: "only needed for decoders which are not synchronous"; called by
@@ -191,7 +256,7 @@ static int skipto_rtjpeg_pipe(bgav_stream_t *s, int64_t dest) {
     gavl_source_status_t st = fill_pipeline(s);
     if (mi_rtj_pipe_pending(priv->pipe) == 0) return st == GAVL_SOURCE_AGAIN ? 1 : 0;
     mi_rtj_pipe_peek_tag(priv->pipe, &tag);
-    m = &priv->meta[tag % (uint64_t)priv->depth];
+    m = &priv->meta[tag % MI_RTJ_MAX_DEPTH];
     if (m->pts + m->duration > dest) {
 #ifdef MI_RTJ_HAVE_OUT_TIME
       s->out_time = m->pts;

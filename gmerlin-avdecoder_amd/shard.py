@@ -2,7 +2,7 @@
 
 The path has no exchange step: packets of intra-only streams are independent, and a stream with
 0xFF "unchanged" blocks is independent of every other stream.  So ranks never trade data; the only
-collective is the final reduction of (frames, pixels, mismatches) by SUM and elapsed time by MAX,
+collective is the final reduction of (frames, pixels, mismatches, frames compared) by SUM and elapsed time by MAX,
 a few bytes over RCCL (backend "nccl" on ROCm) or gloo in the CPU tests."""
 from dataclasses import dataclass
 
@@ -28,17 +28,18 @@ class Report:
     pixels: int
     mismatches: int
     elapsed: float
+    checked: int = 0  # frames of this rank compared with the CPU decoder
 
 
 def reduce_report(local, dist=None, device=None, force=False):
     """SUM of frames/pixels/mismatches and MAX of elapsed over all ranks; identity without dist
     (force: run the collectives even in a group of one, to rehearse the backend)."""
     if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
-        return Report(local.frames, local.pixels, local.mismatches, local.elapsed)
+        return Report(local.frames, local.pixels, local.mismatches, local.elapsed, local.checked)
     import torch
     dev = device if device is not None else "cpu"
-    s = torch.tensor([local.frames, local.pixels, local.mismatches], dtype=torch.int64, device=dev)
+    s = torch.tensor([local.frames, local.pixels, local.mismatches, local.checked], dtype=torch.int64, device=dev)
     m = torch.tensor([local.elapsed], dtype=torch.float64, device=dev)
     dist.all_reduce(s, op=dist.ReduceOp.SUM)
     dist.all_reduce(m, op=dist.ReduceOp.MAX)
-    return Report(int(s[0].item()), int(s[1].item()), int(s[2].item()), float(m[0].item()))
+    return Report(int(s[0].item()), int(s[1].item()), int(s[2].item()), float(m[0].item()), int(s[3].item()))

@@ -100,6 +100,11 @@ int mi_rtj_pipe_peek_tag(const mi_rtj_pipe *pipe, uint64_t *tag);
 /* .resync (include/avdec_private.h:110, lib/video.c:561-562): forget everything in flight.  The stream's previous
  * picture stays, as priv->frame does in the reference. */
 int mi_rtj_pipe_flush(mi_rtj_pipe *pipe);
+/* Measurement only (bench.py): per-kernel device time of the packets a session decoded since profiling was switched on
+ * (summed over its slots; indices as MI_RTJ_K_* below).  Switching flushes the session.  Profiling costs the
+ * submitting thread two event records per kernel and packet: use a lap of its own, not a timed region. */
+int mi_rtj_pipe_profile(mi_rtj_pipe *pipe, int enable);
+int mi_rtj_pipe_times(mi_rtj_pipe *pipe, float ms[6], int *launches);
 
 /* Geometry and effective quality the last mi_rtj_decode / plan used (RTjpeg_t width/height/Q). */
 void mi_rtj_get_state(const mi_rtj_ctx *ctx, int *width, int *height, int *quality);

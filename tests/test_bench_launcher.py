@@ -49,19 +49,36 @@ SHARE = {"MI_RTJ_DIST_BACKEND": "gloo", "MI_RTJ_SHARE_DEVICE": "1"}
 
 @pytest.mark.gpu
 def test_two_ranks_on_one_box_report_two_gpus():
-    r = run_bench(["--gpus", "2", "--frames", "128", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-stress", "--no-e2e"],
-                  env=SHARE)
+    """the N > 1 line carries its own evidence: every rank compares a sample of its own output with the CPU decoder
+    (parity_checked = N x sample, through the path's one reduction), rank 0 times the CPU baseline"""
+    r = run_bench(["--gpus", "2", "--frames", "128", "--steps", "3", "--warmup", "1", "--verify-frames", "32",
+                   "--cpu-seconds", "1", "--no-stress", "--no-e2e"], env=SHARE)
     assert r.returncode == 0, r.stderr[-3000:]
     d = last_json(r)
     assert d["n_gpus"] == 2 and d["config"]["frames_per_gpu"] == 128 and d["value"] > 0
+    assert d["parity_checked"] == 2 * 32 and d["parity_sample_per_rank"] == 32 and d["parity_mismatches"] == 0
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] == 1
+    assert d["cpu_baseline_all_cores"]["value"] > 0
+    assert d["roofline"]["frac"] > 0
+
+
+def test_selftest_reduction_carries_the_frames_compared():
+    """(CPU, gloo) the reduction sums what every rank compared"""
+    sys.path.insert(0, ROOT)
+    import importlib
+    shard = importlib.import_module("gmerlin-avdecoder_amd.shard")
+    rep = shard.reduce_report(shard.Report(10, 1000, 1, 2.0, 32))
+    assert (rep.frames, rep.pixels, rep.mismatches, rep.elapsed, rep.checked) == (10, 1000, 1, 2.0, 32)
 
 
 @pytest.mark.gpu
 def test_one_rank_line_checks_every_sampled_frame_and_carries_the_extras():
-    r = run_bench(["--frames", "64", "--steps", "3", "--warmup", "1", "--cpu-seconds", "1", "--verify-frames", "64"])
+    r = run_bench(["--frames", "512", "--steps", "3", "--warmup", "1", "--cpu-seconds", "1", "--verify-frames", "64"])
     assert r.returncode == 0, r.stderr[-3000:]
     d = last_json(r)
     assert d["parity_checked"] == 64 and d["parity_mismatches"] == 0
+    assert set(d["by_batch"]) >= {"256", "512"} and d["by_batch"]["256"]["frames_per_s"] > 0
+    assert "k_synth" in d["config"]["workload"]
     assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline_all_cores"]["cores"] >= 1
     assert d["median_step"]["device_ms"] > 0 and d["roofline"]["frac"] > 0
     assert d["kernels"]["k_decode"]["gbs"] > 0
@@ -79,4 +96,7 @@ def test_other_bench_configurations(cfg, extra):
         assert r.returncode == 0, r.stderr[-3000:]
         d = last_json(r)
         assert d["n_gpus"] == gpus and d["parity_mismatches"] == 0 and d["parity_checked"] > 0 and d["value"] > 0
+        assert d["roofline"]["frac"] >= 0 and d["roofline"]["kernel"] and d["cpu_baseline"]["value"] > 0
+        if cfg == "streams4k":  # the whole first lap of every stream is compared (8 packets here)
+            assert d["parity_checked"] == 8 * gpus
         assert cfg.replace("streams4k", "3840x2160").replace("mixed", "mixed") in d["metric"] or cfg == "mixed"

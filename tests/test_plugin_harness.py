@@ -199,3 +199,76 @@ def test_pipelined_decoder_refuses_a_packet_of_another_size(tmp_path):
     assert len(recs) == 5
     for (got, _), (planes, _) in zip(recs, want):
         assert np.array_equal(got, planes)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("inside", [4, 5, 7])
+def test_pipelined_decoder_skip_target_inside_the_read_ahead_window(tmp_path, inside):
+    """with six packets in flight, a skip after 3 pictures to a time inside picture 4, 5 or 7 — all of
+    them on the device already — must deliver exactly that picture next, as the synchronous reference decoder does.
+    The read-ahead decoder marks its stream GAVL_COMPRESSION_HAS_P_FRAMES, so bgav_video_skipto hands it the exact
+    target (.skipto, lib/video.c:614-634) instead of skipping packets behind its back."""
+    build_harness()
+    w, h = 320, 240
+    enc = R.OracleEncoder(w, h, 200)
+    pkts = [enc.encode(R.synth_frame(w, h, i, seed=9, amp=10)) for i in range(20)]
+    r, recs = run_pipe(tmp_path, pkts, w, h, f"skipto=3:{1000 + 40 * inside + 7}", depth=6)
+    assert r.returncode == 0, r.stderr
+    want = expected_stream(pkts, w, h, w, h, 0)
+    order = list(range(3)) + list(range(inside, 20))
+    assert [pts for _, pts in recs] == [want[i][1] for i in order]
+    for (got, _), i in zip(recs, order):
+        assert np.array_equal(got, want[i][0]), i
+
+
+@pytest.mark.gpu
+def test_source_side_skip_without_a_jump_in_time_stamps_drops_nothing(tmp_path):
+    """the defensive rule for a library that skips packets at the source all the same: only a jump in the time
+    stamps of the packets read proves that something was skipped; a target inside the read-ahead window skips
+    nothing at the source, and no picture may be lost (round 2's rule lost up to depth - 1)"""
+    build_harness()
+    w, h = 320, 240
+    enc = R.OracleEncoder(w, h, 200)
+    pkts = [enc.encode(R.synth_frame(w, h, i, seed=10, amp=10)) for i in range(16)]
+    r, recs = run_pipe(tmp_path, pkts, w, h, f"skippkts=3:{1000 + 40 * 5 + 1}", depth=6)
+    assert r.returncode == 0, r.stderr
+    want = expected_stream(pkts, w, h, w, h, 0)
+    assert [pts for _, pts in recs] == [want[i][1] for i in range(16)]
+
+
+@pytest.mark.gpu
+def test_option_keys_come_before_the_environment(tmp_path):
+    """device and depth are read from the stream's options dictionary (s->opt, as lib/video_v4l2_m2m.c:66 reads
+    BGAV_OPT_VIDEOBUFFER), the environment is the fallback: a device that does not exist fails init whatever
+    MI_RTJ_DEVICE says; a depth given as an option decodes the stream like any other"""
+    build_harness()
+    w, h = 160, 128
+    enc = R.OracleEncoder(w, h, 200, 3, 2, 2)
+    pkts = [enc.encode(R.synth_frame(w, h, i // 2, seed=11, amp=6)) for i in range(9)]
+    pk, out = tmp_path / "p.bin", tmp_path / "o.bin"
+    write_packets(pk, pkts)
+    env = dict(os.environ, MI_RTJ_DEVICE="0", MI_RTJ_DEPTH="64")
+    r = subprocess.run([PIPE, str(pk), str(w), str(h), str(out), "opt=mi355x-device:63"], capture_output=True, text=True, env=env)
+    assert r.returncode == 4 and "Cannot open MI355X decoder" in r.stderr
+    r, recs = run_pipe(tmp_path, pkts, w, h, "opt=mi355x-depth:2", "opt=mi355x-device:0")
+    assert r.returncode == 0, r.stderr
+    want = expected_stream(pkts, w, h, w, h, 0)
+    assert len(recs) == len(want) and all(np.array_equal(g, p) for (g, _), (p, _) in zip(recs, want))
+
+
+@pytest.mark.gpu
+def test_two_streams_on_two_threads(tmp_path):
+    """two decoder instances on two threads of one process (doc/mainpage.incl:54-55), each playing the packet list:
+    both deliver every picture (bench mode counts them)"""
+    import json
+    build_harness()
+    w, h = 320, 240
+    enc = R.OracleEncoder(w, h, 200)
+    pkts = [enc.encode(R.synth_frame(w, h, i, seed=12, amp=10)) for i in range(12)]
+    pk = tmp_path / "p.bin"
+    write_packets(pk, pkts)
+    r = subprocess.run([PIPE, str(pk), str(w), str(h), "/dev/null", "bench=1", "streams=2", "repeat=5"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["streams"] == 2 and d["frames"] == 2 * 12 * 5

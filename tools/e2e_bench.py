@@ -9,7 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(width=1920, height=1088, packets=64, repeat=32, depth=4, quality=255, amp=8, flavours=("", "_nocopy", "_pipe")):
+def run(width=1920, height=1088, packets=64, repeat=32, depth=6, quality=255, amp=8, flavours=("", "_nocopy", "_pipe"),
+        two_streams=True):
     P = importlib.import_module("gmerlin-avdecoder_amd")
     dev = P.MiRtj(0)
     d_fr = dev.synth(width, height, 0, packets, seed=12345, amp=amp)
@@ -33,11 +34,19 @@ def run(width=1920, height=1088, packets=64, repeat=32, depth=4, quality=255, am
         env = dict(os.environ, MI_RTJ_DEPTH=str(depth))
         ih = height - 8 if height == 1088 else height
         r = subprocess.run([exe, path, str(width), str(ih), "/dev/null", f"repeat={repeat}", "bench=1"], capture_output=True, text=True, env=env, timeout=600)
-        name = {"": "copy (synchronous, caller's planes)", "_nocopy": "frame-owning (synchronous)", "_pipe": f"frame-owning, {depth} packets in flight"}[fl]
+        name = {"": "copy (synchronous, caller's planes; -DMI_RTJ_COPY_MODE)", "_nocopy": "frame-owning (synchronous; -DMI_RTJ_SYNC_NOCOPY)",
+                "_pipe": f"frame-owning, {depth} packets in flight (the default build)"}[fl]
         try:
             out[name] = json.loads(r.stdout.strip().splitlines()[-1])
         except Exception:
             out[name] = {"error": (r.stderr or r.stdout)[-300:]}
+        if fl == "_pipe" and two_streams:  # two decoder instances on two threads of one process: the aggregate
+            r = subprocess.run([exe, path, str(width), str(ih), "/dev/null", f"repeat={repeat}", "bench=1", "streams=2"],
+                               capture_output=True, text=True, env=env, timeout=600)
+            try:
+                out["two_streams_two_threads"] = json.loads(r.stdout.strip().splitlines()[-1])
+            except Exception:
+                out["two_streams_two_threads"] = {"error": (r.stderr or r.stdout)[-300:]}
     os.remove(path); os.rmdir(tmp)
     return out
 
@@ -46,6 +55,6 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--width", type=int, default=1920); ap.add_argument("--height", type=int, default=1088)
     ap.add_argument("--packets", type=int, default=64); ap.add_argument("--repeat", type=int, default=32)
-    ap.add_argument("--depth", type=int, default=4)
+    ap.add_argument("--depth", type=int, default=6)
     a = ap.parse_args()
     print(json.dumps(run(a.width, a.height, a.packets, a.repeat, a.depth)))
