@@ -84,7 +84,7 @@ struct mi_rtj_plan {
   std::vector<uint32_t> h_spec_base;       // [n + 1]
   SpecChunkDev* d_spec_chunks = nullptr;
   uint32_t* d_spec_base = nullptr;
-  uint16_t* d_spec_rec = nullptr;          // [walkers][kSpecCap]
+  uint32_t* d_spec_rec = nullptr;          // the walkers' start bits: spec_bits_words(walkers) dwords, [wave][tile][lane][4]
   uint32_t* d_spec_nrec = nullptr;
   uint32_t* d_spec_wstart = nullptr;       // [walkers]: first byte each walker parsed (repairs move it)
   uint2* d_spec_hand = nullptr;            // [walkers]: where a chunk takes over / where the next one has to
@@ -307,7 +307,7 @@ int plan_alloc_chunks(mi_rtj_plan* p) {
         p->cap_spec = 0;  // a failed hipMalloc below must not leave freed pointers behind
       }
       HIPCHK(c, hipMalloc((void**)&p->d_spec_chunks, sizeof(SpecChunkDev) * p->n_spec));
-      HIPCHK(c, hipMalloc((void**)&p->d_spec_rec, sizeof(uint16_t) * kSpecCap * ((p->n_spec + 1 + 63) / 64 * 64)));  // whole waves of walkers, + a spare walker for idle lanes
+      HIPCHK(c, hipMalloc((void**)&p->d_spec_rec, sizeof(uint32_t) * spec_bits_words(p->n_spec)));  // whole waves of walkers, + a spare walker for idle lanes
       HIPCHK(c, hipMalloc((void**)&p->d_spec_nrec, sizeof(uint32_t) * p->n_spec));
       HIPCHK(c, hipMalloc((void**)&p->d_spec_wstart, sizeof(uint32_t) * p->n_spec));
       HIPCHK(c, hipMalloc((void**)&p->d_spec_hand, sizeof(uint2) * p->n_spec));

@@ -127,20 +127,15 @@ __device__ __forceinline__ void walk_blocks(const FrameDev& f, const uint8_t* __
 }
 
 // The same walk, bounded by position instead of block count, for the speculative index's repairs
-// (rtj_spec_kernels.h): from byte p_start, taken to start a macroblock, every block start below `limit` is
-// recorded as a 16-bit offset from p_start (the first record is 0).  Returns the number of blocks seen;
-// only the first `cap` are stored.
-// take / tail: (index << 16 | offset) of the last unit-aligned record below `mid` / below `limit`, the unit being
+// (rtj_spec_kernels.h): from byte p_start, taken to start a macroblock, every block start below `limit` sets its bit in
+// `bits` (LDS, zeroed by the caller; bit 31 - i of dword k = position 32 k + i relative to p_start, the first start
+// is position 0; starts at or past `span` relative positions are counted but not marked).  Returns the number of blocks.
+// take / tail: (index << 16 | offset) of the last unit-aligned start below `mid` / below `limit`, the unit being
 // the macroblock, or the block when lb8 == cb8.
 __device__ __forceinline__ uint32_t walk_record(const FrameDev& f, const uint8_t* __restrict__ stream,
                                                 const QTab* __restrict__ lut, uint32_t p_start, uint32_t mid,
-                                                uint32_t limit, uint16_t* __restrict__ out, uint32_t cap,
-                                                uint32_t& take, uint32_t& tail, uint32_t walker = 0,
-                                                bool interleaved = false) {
-  // where record i of `walker` lives relative to `out` (see spec_rec_index, rtj_spec_kernels.h); plain rows otherwise
-  auto at = [&](uint32_t i) -> size_t {
-    return interleaved ? ((size_t)(i >> 3) * 64u + (walker & 63u)) * 8u + (i & 7u) : (size_t)i;
-  };
+                                                uint32_t limit, uint32_t* bits, uint32_t span, uint32_t& take,
+                                                uint32_t& tail) {
   const int lane = threadIdx.x & 63;
   const uint8_t* g = stream + f.data_off;
   const uint32_t len = f.data_len;
@@ -154,7 +149,7 @@ __device__ __forceinline__ uint32_t walk_record(const FrameDev& f, const uint8_t
            pf3 = fetch(base + 256u);
   uint32_t Wc = wave_incl_scan(token_weight(cur));
   uint32_t Wn = wave_incl_scan(token_weight(nxt)) + (uint32_t)__builtin_amdgcn_readlane((int)Wc, 63);
-  uint32_t p = p_start, ph = 0, acc = 0, k = 0;
+  uint32_t p = p_start, ph = 0, k = 0;
   const bool by_block = lb8 == cb8;
   take = tail = 0;
   while (p < limit) {
@@ -173,10 +168,9 @@ __device__ __forceinline__ uint32_t walk_record(const FrameDev& f, const uint8_t
       pf3 = fetch(base + 256u);
       Wn = wave_incl_scan(token_weight(nxt)) + (uint32_t)__builtin_amdgcn_readlane((int)Wc, 63);
     }
-    acc = (uint32_t)lane == (k & 63u) ? p - p_start : acc;
-    if ((k & 63u) == 63u) {
-      const uint32_t idx = (k & ~63u) + (uint32_t)lane;
-      if (idx < cap) out[at(idx)] = (uint16_t)acc;
+    {
+      const uint32_t rel = p - p_start;  // wave-uniform: one lane marks it
+      if (lane == 0 && rel < span) bits[rel >> 5] |= 0x80000000u >> (rel & 31u);
     }
     k++;
     const uint32_t lp = p - base;
@@ -201,10 +195,6 @@ __device__ __forceinline__ uint32_t walk_record(const FrameDev& f, const uint8_t
       e = 64u + (uint32_t)__builtin_ctzll(mn);  // W grows by >= 1 per byte, so mn != 0
     }
     p = base + e + 1u;
-  }
-  if (k & 63u) {  // the last, partial group of records
-    const uint32_t idx = (k & ~63u) + (uint32_t)lane;
-    if (idx < k && idx < cap) out[at(idx)] = (uint16_t)acc;
   }
   return k;
 }

@@ -10,8 +10,9 @@
 //
 //   k_spec_walk    one LANE per chunk (2048 bytes): starts kSpecLead bytes before its chunk, assuming a macroblock
 //                  starts there, and runs RTjpeg_s2b's length rule (lib/RTjpeg.c:157-186, 2704) as a
-//                  byte-serial state machine over lead + chunk, recording every block start.
-//                  64 chunks advance in lockstep per wave: ~20 vector instructions per byte for 64
+//                  byte-serial state machine over lead + chunk, recording every block start as ONE BIT per stream
+//                  byte (round 3; 16-bit positions through an LDS ring before).
+//                  64 chunks advance in lockstep per wave: 15 vector instructions per byte for 64
 //                  streams, against ~20 per BLOCK POSITION AND TYPE in k_index_summarize.
 //   k_spec_verify  per packet: the last (macro)block start a walker saw in its lead, i.e. before its
 //                  chunk, must be the last one its predecessor saw before the end of its span, which is
@@ -48,27 +49,25 @@ constexpr int kSpecLead = MIRTJ_SPEC_LEAD;   // bytes it parses before them, fro
 constexpr int kSpecLeadLong = MIRTJ_SPEC_LEAD_LONG;  // the lead of the second walker form, for content that falls into step late
 constexpr int kSpecSpan = kSpecLeadLong + kSpecChunk;  // the longest span a walker parses
 constexpr int kSpecTile = 128;    // bytes per lane fetched at a time (one cache line)
-constexpr int kSpecCap = 2048;    // block starts a walker can record (16-bit, relative to its first byte):
-                                  // enough for blocks of 1.75 bytes on average over its span
-// Where a walker's records live.  MIRTJ_SPEC_REC_INTERLEAVE == 0: a row of kSpecCap records per walker (4 KB, of which
-// a tenth is used: the 64 lanes of a wave store 16 bytes each into 64 rows 4 KB apart).  == 1: the 64 walkers of a
-// wave share one region of 64 * kSpecCap records, laid out [group of 8 records][lane][8]: what a wave stores at a time
-// is contiguous, and the region fills from its start.
-#ifndef MIRTJ_SPEC_REC_INTERLEAVE
-#define MIRTJ_SPEC_REC_INTERLEAVE 1
-#endif
-constexpr bool kSpecRecInterleave = MIRTJ_SPEC_REC_INTERLEAVE != 0;
-__host__ __device__ constexpr size_t spec_rec_base(uint32_t walker) {  // in records, from the start of the buffer
-  return kSpecRecInterleave ? (size_t)(walker >> 6) * (64u * (size_t)kSpecCap) : (size_t)walker * (size_t)kSpecCap;
+// What a walker records: one START BIT per byte of its span — bit (31 - i) of dword k says that a block starts at
+// walker-relative position 32 k + i (the walker's first byte is taken to start one).  The walker shifts the "previous
+// byte ended a block" mask into a register with one add-with-carry per byte and stores 16 bytes per 128-byte tile; the
+// 64 walkers of a wave share a region laid out [tile][lane] (what a wave stores at a time is 1 KB of contiguous
+// memory).  Round 2 recorded 16-bit positions through a 32-entry LDS ring: two more vector instructions and an LDS
+// write per byte, flush checks every 16 bytes, 4 KB reserved per walker and a cap of 2048 blocks per span; the bits
+// cost k_spec_verify a rank-to-position step per chunk (a popcount scan over at most 112 dwords) and need no cap.
+constexpr int kSpecTilesMax = kSpecSpan / kSpecTile;  // tiles of the longest span: a walker's bits are 16 bytes per tile
+__host__ __device__ constexpr size_t spec_bits_words(uint64_t walkers) {  // dwords of the bit buffer (+ a spare walker)
+  return (size_t)((walkers + 1 + 63) / 64) * (size_t)kSpecTilesMax * 64u * 4u;
 }
-__host__ __device__ constexpr size_t spec_rec_index(uint32_t walker, uint32_t i) {
-  return spec_rec_base(walker) +
-         (kSpecRecInterleave ? ((size_t)(i >> 3) * 64u + (walker & 63u)) * 8u + (i & 7u) : (size_t)i);
+// dword k (positions 32 k .. 32 k + 31) of a walker's bits, in dwords from the start of the buffer
+__host__ __device__ constexpr size_t spec_bits_dword(uint32_t walker, uint32_t k) {
+  return (((size_t)(walker >> 6) * (size_t)kSpecTilesMax + (k >> 2)) * 64u + (walker & 63u)) * 4u + (k & 3u);
 }
 constexpr uint64_t kSpecMinWalkers = 40000;  // below this (~100 MB of packets) the exact kernels index a batch faster:
                                             // a walker is one lane and runs ~0.35 ms whatever the batch (host policy)
-constexpr int kSpecRingRow = 64 + 16;       // LDS bytes per lane of the record ring: 32 records + bank padding
-constexpr int kSpecRow = kSpecTile + 16;  // LDS bytes per lane: tile + the dword after it + bank padding
+constexpr int kSpecRingRow = 64 + 16;       // LDS bytes per lane: the start bits of the last four tiles (512 bytes of
+                                            // stream: more than a macroblock, 384) + bank padding
 static_assert(kSpecSpan % kSpecTile == 0 && kSpecSpan < 65536, "walker span: whole tiles, 16-bit positions");
 static_assert(kSpecLead >= 6 * 64 + 64 && kSpecLead % kSpecTile == 0 && kSpecChunk % kSpecTile == 0, "the lead: at least one whole macroblock, whole tiles");
 static_assert(kSpecLeadLong >= kSpecLead && kSpecLeadLong % kSpecTile == 0 && kSpecLeadLong <= kSpecChunk,
@@ -94,70 +93,69 @@ constexpr int kSpecQuietLaunches = 16;  // that many of them in a row and the pl
 #ifndef MIRTJ_SPEC_VER_BATCH
 #define MIRTJ_SPEC_VER_BATCH 4
 #endif
+constexpr int kSpecVerWindow = 512;  // ranks a wave of k_spec_verify orders in LDS at a time (a chunk of ordinary content: ~200)
 constexpr int kSpecVerBatch = MIRTJ_SPEC_VER_BATCH;  // chunks whose records a wave of k_spec_verify copies side by side
 constexpr int kSpecVerThreads = MIRTJ_SPEC_VER_THREADS;  // k_spec_verify: chunks of a packet handled side by side  // grid rows of the exact kernels when they only serve refused packets
 
-// One byte of the walker's state machine, spelled out: 17 vector instructions (the compiler's version of
-// the same C++ had 21-22: it keeps lane masks as 0/1 integers and splits the counters).  State: u = units
-// of the current block so far, q = 5 - (block number within the macroblock), rb = DC + raw bytes of the
-// current block's type, cnt = records so far, em = lane mask "the previous byte ended a block".  The next
-// block's start `val` goes to ring slot cnt % 32 on every byte; cnt only moves on when this byte ends its
-// block.  gfx950 wants two instructions between a vector compare and the use of its mask; the order below
-// provides them without s_nop.
-#define MIRTJ_SPEC_STEP(SEL)                                                                                      \
-  asm("v_sub_u32_sdwa %[t], sext(%[w]), %[k63] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SEL               \
-      " src1_sel:DWORD\n\t"                                                                                       \
-      "v_cmp_eq_i32_e32 vcc, %[kn64], %[t]\n\t"         /* the byte is 0xFF */                                     \
-      "v_cmp_lt_i32_e64 %[ma], %[u], %[rb]\n\t"         /* a DC or raw byte */                                     \
-      "v_max_i32_e32 %[wt], 1, %[t]\n\t"                /* token weight (lib/RTjpeg.c:171-182) */                  \
+// One byte of the walker's state machine, spelled out: 15 vector instructions (the compiler's version of the same C++
+// had 21-22: it keeps lane masks as 0/1 integers and splits the counters; round 2's, with 16-bit records, 17 and an LDS
+// write).  State: u = units of the current block so far, q = 5 - (block number within the macroblock), rb = DC + raw
+// bytes of the current block's type, em = lane mask "the previous byte ended a block" = "a block starts at this byte",
+// bits = the start bits of the 32 bytes in hand (shifted in with one add-with-carry).  The byte's token value t = byte - 63
+// and max(1, t) arrive precomputed (tm, wtm) and the macro computes them for the NEXT byte (byte NSEL of word wn): that
+// is independent work to put into the two wait states gfx950 wants between a vector compare that writes a lane mask
+// and a vector instruction that reads it (the assembler pads nothing inside an asm statement).  Checked gaps: vcc (a) ->
+// s_and: b, c; ma (b) -> g: c .. f; em (i) -> l: j + s_nop; mx (m) -> p: n, o; my (n) -> q: o, p.
+#define MIRTJ_SPEC_STEP(NSEL)                                                                                     \
+  asm("v_cmp_eq_i32_e32 vcc, %[kn64], %[tm]\n\t"        /* a: the byte is 0xFF */                                  \
+      "v_cmp_lt_i32_e64 %[ma], %[u], %[rb]\n\t"         /* b: a DC or raw byte */                                  \
+      "v_addc_co_u32_e64 %[bits], %[mz], %[bits], %[bits], %[em]\n\t" /* c: bits = bits << 1 | starts-here */     \
       "s_and_b64 vcc, vcc, %[em]\n\t"                   /* 0xFF as a block's first byte: one-byte block */        \
-      "v_bfe_u32 %[idx], %[cnt], 0, 5\n\t"                                                                         \
-      "v_cndmask_b32_e64 %[wr], 1, 64, vcc\n\t"                                                                    \
-      "v_cndmask_b32_e64 %[wt], %[wt], %[wr], %[ma]\n\t"                                                           \
-      "v_add_u32_e32 %[u], %[u], %[wt]\n\t"                                                                        \
-      "v_cmp_lt_i32_e64 %[em], 63, %[u]\n\t"            /* 64 units: the block ends with this byte */              \
-      "v_lshl_add_u32 %[ra], %[idx], 1, %[ring]\n\t"                                                               \
-      "ds_write_b16 %[ra], %[val]\n\t"                                                                             \
-      "v_subb_co_u32_e64 %[q], vcc, %[q], 0, %[em]\n\t"                                                            \
-      "v_cmp_lt_i32_e64 %[mx], %[q], 0\n\t"             /* past the macroblock's last block */                     \
-      "v_cmp_lt_u32_e64 %[my], %[q], 2\n\t"             /* a chroma block is next */                               \
-      "v_addc_co_u32_e64 %[cnt], vcc, 0, %[cnt], %[em]\n\t"                                                        \
-      "v_cndmask_b32_e64 %[u], %[u], 0, %[em]\n\t"                                                                 \
-      "v_cndmask_b32_e64 %[q], %[q], 5, %[mx]\n\t"                                                                 \
-      "v_cndmask_b32_e64 %[rb], %[lb], %[cb], %[my]"                                                               \
-      : [u] "+v"(u), [cnt] "+v"(cnt), [q] "+v"(q), [rb] "+v"(rb), [em] "+s"(em), [t] "=&v"(t_), [wt] "=&v"(wt_),  \
-        [wr] "=&v"(wr_), [idx] "=&v"(idx_), [ra] "=&v"(ra_), [ma] "=&s"(ma_), [mx] "=&s"(mx_), [my] "=&s"(my_)     \
-      : [w] "v"(w_), [k63] "v"(k63), [kn64] "v"(kn64), [ring] "v"(ring_a), [val] "v"(val_), [lb] "v"(lb), [cb] "v"(cb) \
-      : "vcc", "memory")
+      "v_sub_u32_sdwa %[tn], sext(%[wn]), %[k63] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" NSEL             \
+      " src1_sel:DWORD\n\t"                             /* e: the next byte's token value */                     \
+      "v_cndmask_b32_e64 %[wr], 1, 64, vcc\n\t"         /* f */                                                    \
+      "v_cndmask_b32_e64 %[wt], %[wtm], %[wr], %[ma]\n\t" /* g: token weight (lib/RTjpeg.c:171-182), or 1 / 64 */ \
+      "v_add_u32_e32 %[u], %[u], %[wt]\n\t"             /* h */                                                    \
+      "v_cmp_lt_i32_e64 %[em], 63, %[u]\n\t"            /* i: 64 units: the block ends with this byte */           \
+      "v_max_i32_e32 %[wtn], 1, %[tn]\n\t"              /* j: the next byte's token weight */                     \
+      "s_nop 0\n\t"                                                                                                \
+      "v_subb_co_u32_e64 %[q], vcc, %[q], 0, %[em]\n\t" /* l */                                                    \
+      "v_cmp_lt_i32_e64 %[mx], %[q], 0\n\t"             /* m: past the macroblock's last block */                  \
+      "v_cmp_lt_u32_e64 %[my], %[q], 2\n\t"             /* n: a chroma block is next */                            \
+      "v_cndmask_b32_e64 %[u], %[u], 0, %[em]\n\t"      /* o */                                                    \
+      "v_cndmask_b32_e64 %[q], %[q], 5, %[mx]\n\t"      /* p */                                                    \
+      "v_cndmask_b32_e64 %[rb], %[lb], %[cb], %[my]"    /* q */                                                    \
+      : [u] "+v"(u), [q] "+v"(q), [rb] "+v"(rb), [em] "+s"(em), [bits] "+v"(bits_), [tn] "=&v"(tn_), [wtn] "=&v"(wtn_), \
+        [wt] "=&v"(wt_), [wr] "=&v"(wr_), [ma] "=&s"(ma_), [mx] "=&s"(mx_), [my] "=&s"(my_), [mz] "=&s"(mz_)         \
+      : [tm] "v"(tm_), [wtm] "v"(wtm_), [wn] "v"(wn_), [k63] "v"(k63), [kn64] "v"(kn64), [lb] "v"(lb), [cb] "v"(cb)  \
+      : "vcc")
 
 // The same when every packet of the launch has lb8 == cb8 (two thirds of the qualities): all blocks parse
-// alike, no phase to track, 12 vector instructions.
-#define MIRTJ_SPEC_STEP1(SEL)                                                                                     \
-  asm("v_sub_u32_sdwa %[t], sext(%[w]), %[k63] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SEL               \
-      " src1_sel:DWORD\n\t"                                                                                       \
-      "v_cmp_eq_i32_e32 vcc, %[kn64], %[t]\n\t"                                                                    \
+// alike, no phase to track, 10 vector instructions.
+#define MIRTJ_SPEC_STEP1(NSEL)                                                                                    \
+  asm("v_cmp_eq_i32_e32 vcc, %[kn64], %[tm]\n\t"                                                                   \
       "v_cmp_lt_i32_e64 %[ma], %[u], %[rb]\n\t"                                                                    \
-      "v_max_i32_e32 %[wt], 1, %[t]\n\t"                                                                           \
+      "v_addc_co_u32_e64 %[bits], %[mz], %[bits], %[bits], %[em]\n\t"                                              \
       "s_and_b64 vcc, vcc, %[em]\n\t"                                                                              \
-      "v_bfe_u32 %[idx], %[cnt], 0, 5\n\t"                                                                         \
+      "v_sub_u32_sdwa %[tn], sext(%[wn]), %[k63] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" NSEL             \
+      " src1_sel:DWORD\n\t"                                                                                       \
       "v_cndmask_b32_e64 %[wr], 1, 64, vcc\n\t"                                                                    \
-      "v_cndmask_b32_e64 %[wt], %[wt], %[wr], %[ma]\n\t"                                                           \
+      "v_cndmask_b32_e64 %[wt], %[wtm], %[wr], %[ma]\n\t"                                                          \
       "v_add_u32_e32 %[u], %[u], %[wt]\n\t"                                                                        \
       "v_cmp_lt_i32_e64 %[em], 63, %[u]\n\t"                                                                       \
-      "v_lshl_add_u32 %[ra], %[idx], 1, %[ring]\n\t"                                                               \
-      "ds_write_b16 %[ra], %[val]\n\t"                                                                             \
-      "v_addc_co_u32_e64 %[cnt], vcc, 0, %[cnt], %[em]\n\t"                                                        \
+      "v_max_i32_e32 %[wtn], 1, %[tn]\n\t"                                                                         \
+      "s_nop 0\n\t"                                                                                                \
       "v_cndmask_b32_e64 %[u], %[u], 0, %[em]"                                                                     \
-      : [u] "+v"(u), [cnt] "+v"(cnt), [em] "+s"(em), [t] "=&v"(t_), [wt] "=&v"(wt_), [wr] "=&v"(wr_),              \
-        [idx] "=&v"(idx_), [ra] "=&v"(ra_), [ma] "=&s"(ma_)                                                        \
-      : [w] "v"(w_), [k63] "v"(k63), [kn64] "v"(kn64), [ring] "v"(ring_a), [val] "v"(val_), [rb] "v"(rb)           \
-      : "vcc", "memory")
+      : [u] "+v"(u), [em] "+s"(em), [bits] "+v"(bits_), [tn] "=&v"(tn_), [wtn] "=&v"(wtn_), [wt] "=&v"(wt_),       \
+        [wr] "=&v"(wr_), [ma] "=&s"(ma_), [mz] "=&s"(mz_)                                                          \
+      : [tm] "v"(tm_), [wtm] "v"(wtm_), [wn] "v"(wn_), [k63] "v"(k63), [kn64] "v"(kn64), [rb] "v"(rb)              \
+      : "vcc")
 
 template <bool PHASE, int LEAD>
 __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ frames,
                                                    const SpecChunkDev* __restrict__ chunks, uint32_t total,
                                                    const uint8_t* __restrict__ stream,
-                                                   const QTab* __restrict__ lut, uint16_t* __restrict__ records,
+                                                   const QTab* __restrict__ lut, uint32_t* __restrict__ recbits,
                                                    uint32_t* __restrict__ nrec, uint32_t* __restrict__ wstart,
                                                    uint2* __restrict__ hand, const uint32_t* __restrict__ state) {
   // both forms are launched; the plan's policy state says which one works (none while paused, k_spec_policy)
@@ -201,103 +199,119 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
 
   // ---- the length rule as a branch-free state machine.  A block is complete after 64 units: DC and the
   //      raw bytes count 1 each, a token its weight.  u = units of the current block so far, rb = its
-  //      1 + bt8 DC/raw bytes, ph = its number within the macroblock ----
+  //      1 + bt8 DC/raw bytes, q = 5 - its number within the macroblock ----
   int u = 0, rb = lb;
   uint32_t q = 5;        // 5 - block number within the macroblock
   uint64_t em = ~0ull;   // the walker's first byte is taken to be a macroblock's first
-  // record k = start of the walker's block k (phase k mod 6), 16-bit.  Records are staged in a 32-entry
-  // ring per lane in LDS and leave for HBM eight at a time (one 16-byte store): a 2-byte global store
-  // per block end was 40 % of the kernel.  Idle lanes of the last wave own the spare row after the last
-  // walker's.
-  const uint32_t gw = act ? g : total;  // idle lanes of the last wave own the spare walker after the last one
-  uint8_t* const rec8 = (uint8_t*)records;
-  uint8_t* const ring = s_ring + lane * kSpecRingRow;
-  const uint32_t ring_a = lds_address(ring);
-  const int kn64 = -64;
-  uint32_t cnt = 1, flushed = 0;
-  *(uint16_t*)ring = 0;
-  const int k63 = 63;
-  // pending = cnt - flushed as a signed number: the last, partial group leaves it negative
-  auto flush = [&](int least) {
-    while (__any((int)(cnt - flushed) >= least)) {
-      if ((int)(cnt - flushed) >= least) {
-        const uint4 v = *(const uint4*)(ring + ((flushed & 31u) << 1));  // flushed is a multiple of 8
-        if (flushed <= (uint32_t)kSpecCap - 8u) *(uint4*)(rec8 + 2u * spec_rec_index(gw, flushed)) = v;
-        flushed += 8u;
+  // idle lanes of the last wave own the spare walker after the last one
+  const uint32_t gw = act ? g : total;
+  uint4* const ring = (uint4*)(s_ring + lane * kSpecRingRow);  // the start bits of the last four tiles
+  const int kn64 = -64, k63 = 63;
+  uint32_t cnt = 0;  // block starts recorded so far (counted tile by tile)
+
+  // (index << 16 | position) of the last unit-aligned block start below the start of tile `lt` (walker-relative; the
+  // unit is the macroblock, or the block when lb8 == cb8: k_spec_verify).  Called between tiles: cnt counts the starts
+  // below the limit, the current block has number 5 - q in its macroblock, and if the byte before the limit ended a
+  // block (the lane's bit of em), a start AT the limit is pending that is in neither.  The unit start wanted is at
+  // most a macroblock (384 bytes) back: inside the four tiles the ring holds.
+  const bool by_block = lb == cb;
+  auto last_aligned_below = [&](int lt) -> uint32_t {
+    const int d = (int)((em >> lane) & 1ull);
+    int r = by_block ? 0 : 5 - (int)q - d;  // starts between the one wanted and the limit
+    r = r < 0 ? r + 6 : r;
+    int left = r;
+    for (int back = 1; back <= 4 && back <= lt; back++) {
+      const int tile = lt - back;
+      const uint4 v = ring[tile & 3];
+      const uint32_t dw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 3; j >= 0; j--) {
+        uint32_t m = dw[j];
+        const int c = __builtin_popcount(m);
+        if (left >= 0 && left < c) {
+          for (int k = 0; k < left; k++) m &= m - 1u;  // drop the `left` latest starts of this dword (lowest bits)
+          const uint32_t pos = (uint32_t)(tile * kSpecTile + 32 * j + 31 - __builtin_ctz(m));
+          return ((cnt - 1u - (uint32_t)r) << 16) | pos;
+        }
+        left -= c;
       }
     }
-  };
-
-  // (index << 16 | position) of the last unit-aligned record below `limit` (walker-relative); the unit is the
-  // macroblock, or the block when lb8 == cb8 (k_spec_verify).  Called between bytes: at most the newest
-  // record can sit AT the limit, and the records wanted are among the last seven, i.e. still in the ring.
-  const bool by_block = lb == cb;
-  auto last_aligned_below = [&](uint32_t limit) -> uint32_t {
-    const uint32_t newest = *(const uint16_t*)(ring + (((cnt - 1u) & 31u) << 1));
-    const uint32_t d = newest >= limit ? 1u : 0u, n = cnt - d;
-    // block cnt-1 has phase 5-q, so record n-1 has phase (5-q-d) mod 6: no division (one by a lane-dependent
-    // value, or even by 6, does not get through the compiler next to the SGPR-mask assembly)
-    int r = 5 - (int)q - (int)d;
-    r = r < 0 ? r + 6 : r;
-    const uint32_t idx = n - 1u - (by_block ? 0u : (uint32_t)r);
-    return (idx << 16) | *(const uint16_t*)(ring + ((idx & 31u) << 1));
+    return 0u;  // nothing but the walker's own first byte (record 0, position 0)
   };
   uint32_t take = 0;  // where this walker's chunk takes over from its predecessor (chunk 0: byte 0, record 0)
   uint32_t tail0 = 0;
+  uint32_t* const out_bits = recbits + spec_bits_dword(gw, 0);
+  uint4 tb = make_uint4(0, 0, 0, 0);  // the tile's start bits
 
   request(0);
   for (int t = 0; t < kSpan / kSpecTile; t++) {
     // the tile is parsed out of registers (fully unrolled: 128 byte steps); staging it in LDS for a
     // smaller loop body capped the kernel at 11 waves per CU
     if (t == LEAD / kSpecTile) {  // the chunk begins with this tile
-      const uint32_t v = last_aligned_below((uint32_t)LEAD);
+      const uint32_t v = last_aligned_below(t);
       take = sc.c ? v : 0u;
     }
-    if (t == kSpecChunk / kSpecTile) tail0 = last_aligned_below((uint32_t)kSpecChunk);  // chunk 0 (no lead) ends here
+    if (t == kSpecChunk / kSpecTile) tail0 = last_aligned_below(t);  // chunk 0 (no lead) ends here
     uint32_t cur[33];
 #pragma unroll
     for (int k = 0; k < 33; k++) cur[k] = buf[k];
-    // the records of the tile before leave now, BEFORE the next tile's loads are queued: loads and stores
-    // complete in order, so a store queued after those loads would have to be waited for with them (-3 %)
-    flush(8);
+    // the bits of the tile before leave now, BEFORE the next tile's loads are queued: loads and stores
+    // complete in order, so a store queued after those loads would have to be waited for with them
+    if (t > 0) *(uint4*)(out_bits + (size_t)(t - 1) * 256u) = tb;
     if (t + 1 < kSpan / kSpecTile) request(t + 1);  // in flight while this tile is parsed
+    // the first byte's token value and weight; every step computes them for the byte after it
+    int tm_, wtm_;
+    {
+      const uint32_t w0 = __builtin_amdgcn_alignbyte(cur[1], cur[0], sh);
+      tm_ = (int)(int8_t)(w0 & 0xFFu) - 63;
+      wtm_ = tm_ > 1 ? tm_ : 1;
+    }
+    uint32_t bw[4];
 #pragma unroll
     for (int i = 0; i < kSpecTile / 16; i++) {
-      const uint32_t wd[4] = {__builtin_amdgcn_alignbyte(cur[4 * i + 1], cur[4 * i], sh),
+      const uint32_t wd[5] = {__builtin_amdgcn_alignbyte(cur[4 * i + 1], cur[4 * i], sh),
                               __builtin_amdgcn_alignbyte(cur[4 * i + 2], cur[4 * i + 1], sh),
                               __builtin_amdgcn_alignbyte(cur[4 * i + 3], cur[4 * i + 2], sh),
-                              __builtin_amdgcn_alignbyte(cur[4 * i + 4], cur[4 * i + 3], sh)};
-      const uint32_t pos = (uint32_t)(t * kSpecTile + 16 * i);  // walker-relative position of wd's first byte
+                              __builtin_amdgcn_alignbyte(cur[4 * i + 4], cur[4 * i + 3], sh),
+                              // the word after them, for the step that looks one byte ahead (the tile's last byte
+                              // looks at a byte that is never used: the next tile starts afresh)
+                              i + 1 < kSpecTile / 16 ? __builtin_amdgcn_alignbyte(cur[4 * i + 5], cur[4 * i + 4], sh) : 0u};
+      uint32_t bits_ = (i & 1) ? bw[i >> 1] : 0u;  // 32 steps shift every older bit out: no need to clear
 #pragma unroll
       for (int b = 0; b < 16; b++) {
-        const uint32_t w_ = wd[b >> 2], val_ = pos + (uint32_t)b + 1u;  // the next block would start at pos + b + 1
-        int t_, wt_, wr_;
-        uint32_t idx_, ra_;
-        uint64_t ma_, mx_, my_;
+        const uint32_t wn_ = wd[(b + 1) >> 2];
+        int tn_, wtn_, wt_, wr_;
+        uint64_t ma_, mx_, my_, mz_;
         if (PHASE) {
-          switch (b & 3) {
+          switch ((b + 1) & 3) {
             case 0: MIRTJ_SPEC_STEP("BYTE_0"); break;
             case 1: MIRTJ_SPEC_STEP("BYTE_1"); break;
             case 2: MIRTJ_SPEC_STEP("BYTE_2"); break;
             default: MIRTJ_SPEC_STEP("BYTE_3"); break;
           }
         } else {
-          switch (b & 3) {
+          switch ((b + 1) & 3) {
             case 0: MIRTJ_SPEC_STEP1("BYTE_0"); break;
             case 1: MIRTJ_SPEC_STEP1("BYTE_1"); break;
             case 2: MIRTJ_SPEC_STEP1("BYTE_2"); break;
             default: MIRTJ_SPEC_STEP1("BYTE_3"); break;
           }
         }
+        tm_ = tn_;
+        wtm_ = wtn_;
       }
-      flush(16);  // inside a tile only when the ring is half full: at most 15 + 16 records are staged at this point
+      bw[i >> 1] = bits_;
     }
+    tb = make_uint4(bw[0], bw[1], bw[2], bw[3]);
+    ring[t & 3] = tb;
+    cnt += (uint32_t)(__builtin_popcount(bw[0]) + __builtin_popcount(bw[1]) + __builtin_popcount(bw[2]) +
+                      __builtin_popcount(bw[3]));
   }
-  flush(1);  // the last, partial group (the slots past cnt are never read)
+  *(uint4*)(out_bits + (size_t)(kSpan / kSpecTile - 1) * 256u) = tb;
   if (act) {
-    nrec[g] = cnt;  // > kSpecCap: the span held more blocks than a walker records
+    nrec[g] = cnt;
     wstart[g] = start;
-    const uint32_t tail = last_aligned_below((uint32_t)kSpan);
+    const uint32_t tail = last_aligned_below(kSpan / kSpecTile);
     hand[g] = make_uint2(take, sc.c ? tail : tail0);  // .y: what the next chunk must take over from
   }
 }
@@ -308,7 +322,7 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
 __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev* __restrict__ frames,
                                                       const uint32_t* __restrict__ spec_base,
                                                       const QTab* __restrict__ lut,
-                                                      const uint16_t* __restrict__ records,
+                                                      const uint32_t* __restrict__ recbits,
                                                       const uint32_t* __restrict__ nrec, uint32_t* __restrict__ blkoff,
                                                       uint32_t* __restrict__ ok, uint32_t* __restrict__ todo,
                                                       uint32_t* __restrict__ ntodo, const uint32_t* __restrict__ state,
@@ -322,6 +336,7 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
   if (pass == 2 && ok[blockIdx.x] != 2u) return;  // the second pass only looks at packets with repaired chunks
   __shared__ uint32_t s_wave[kSpecVerThreads / 64], s_carry[3];  // carry: [1] blocks so far, [2] bad
   __shared__ uint32_t s_i0[kSpecVerThreads], s_base[kSpecVerThreads], s_cnt[kSpecVerThreads];
+  __shared__ uint16_t s_pos[kSpecVerThreads / 64][kSpecVerWindow];  // per wave: block offsets in rank order, on their way out
   const FrameDev f = frames[blockIdx.x];
   const uint32_t sc0 = spec_base[blockIdx.x], nsc = spec_base[blockIdx.x + 1] - sc0;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -342,13 +357,11 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
       // The walkers left, per chunk, the last unit-aligned record before the chunk (hand.x: where it takes
       // over; record 0, its arbitrary first byte, if it saw no other) and the last one before the end of the
       // span (hand.y: where the next chunk has to take over), each as index << 16 | position.
-      const uint32_t full = nrec[sc0 + c], n = min(full, (uint32_t)kSpecCap);
+      const uint32_t n = nrec[sc0 + c];  // block starts in the walker's span (fewer than 2^16: a span is under 4 KB)
       const uint2 mine = hand[sc0 + c];
-      bad = full > (uint32_t)kSpecCap;  // the walker ran out of slots
       i0 = c ? mine.x >> 16 : 0u;
       uint32_t i1 = n;  // the packet's last walker: everything it saw (bytes past the packet read as 0)
       if (c + 1 < nsc) {
-        if (nrec[sc0 + c + 1] > (uint32_t)kSpecCap) bad = 1;
         const uint32_t h = wstart[sc0 + c + 1] + (hand[sc0 + c + 1].x & 0xFFFFu);  // where chunk c + 1 took over
         const uint32_t t = wstart[sc0 + c] + (mine.y & 0xFFFFu);                    // where it had to
         i1 = mine.y >> 16;
@@ -383,12 +396,14 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
     // counts of refused chunks are 0, everything is clipped to the packet's own index, and the exact
     // kernels rewrite it)
     const uint32_t tile_n = min((uint32_t)kSpecVerThreads, nsc - c0);
-    // A chunk holds ~200 blocks, i.e. one round trip of four 2-byte gathers per lane; a wave works on
-    // kSpecVerBatch chunks at a time so that it waits for memory once per batch, not once per chunk.
+    // A chunk's block starts are bits in its walker's record: at most kSpecTilesMax * 4 = 112 dwords, two per lane.
+    // Rank of a bit = starts before it (popcounts, one wave scan per half); the ranks first .. first + m - 1 are this
+    // chunk's blocks.  A wave works on kSpecVerBatch chunks at a time so that it waits for memory once per batch.
     constexpr uint32_t kWaves = kSpecVerThreads / 64;
+    static_assert(kSpecTilesMax * 4 <= 128, "two dwords of start bits per lane");
     for (uint32_t j0 = (uint32_t)wv; j0 < tile_n; j0 += kSpecVerBatch * kWaves) {
-      uint32_t base[kSpecVerBatch], m[kSpecVerBatch], start[kSpecVerBatch], first[kSpecVerBatch], mmax = 0;
-      uint32_t R[kSpecVerBatch];  // the walker whose records are copied
+      uint32_t base[kSpecVerBatch], m[kSpecVerBatch], start[kSpecVerBatch], first[kSpecVerBatch];
+      uint32_t w0[kSpecVerBatch], w1[kSpecVerBatch];
 #pragma unroll
       for (int u = 0; u < kSpecVerBatch; u++) {
         const uint32_t j = min(j0 + (uint32_t)u * kWaves, tile_n - 1u);
@@ -396,27 +411,56 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
         base[u] = s_base[j];
         m[u] = have && base[u] <= last ? min(s_cnt[j], last + 1u - base[u]) : 0u;  // clipped to the packet's own index
         start[u] = wstart[sc0 + c0 + j];
-        R[u] = sc0 + c0 + j;
         first[u] = s_i0[j];
-        mmax = max(mmax, m[u]);
+        const uint32_t R = sc0 + c0 + j;  // the walker whose starts are copied
+        w0[u] = m[u] ? recbits[spec_bits_dword(R, (uint32_t)lane)] : 0u;
+        w1[u] = m[u] && lane + 64 < kSpecTilesMax * 4 ? recbits[spec_bits_dword(R, (uint32_t)lane + 64u)] : 0u;
       }
-      for (uint32_t k0 = 0; k0 < mmax; k0 += 256) {
-        uint32_t v[kSpecVerBatch][4];
 #pragma unroll
-        for (int u = 0; u < kSpecVerBatch; u++) {
-#pragma unroll
-          for (int t = 0; t < 4; t++) {
-            const uint32_t k = k0 + 64u * (uint32_t)t + (uint32_t)lane;
-            v[u][t] = k < m[u] ? records[spec_rec_index(R[u], first[u] + k)] : 0u;
+      for (int u = 0; u < kSpecVerBatch; u++) {
+        if (m[u] == 0u) continue;  // wave-uniform
+        const uint32_t c0_ = (uint32_t)__builtin_popcount(w0[u]), c1_ = (uint32_t)__builtin_popcount(w1[u]);
+        const uint32_t in0 = wave_incl_scan(c0_);
+        const uint32_t tot0 = (uint32_t)__builtin_amdgcn_readlane((int)in0, 63);
+        const uint32_t in1 = wave_incl_scan(c1_) + tot0;
+        // rank relative to the chunk's first block (negative: a start of the lead, before the hand-over point)
+        uint32_t* const o = out + base[u];
+        const uint32_t q0 = 32u * (uint32_t)lane, q1 = q0 + 2048u;  // walker-relative position of the dwords' first byte
+        // Ranks are scattered over the lanes (a lane owns the starts of its 32 bytes), the index wants them in order:
+        // written straight to memory, a store instruction touched a dozen 64-byte pieces for 64 offsets and the kernel
+        // took 2.1 ms per 16384 pictures.  The offsets are therefore put in rank order in LDS (scattered 16-bit writes
+        // are cheap there) and leave as whole 256-byte rows, kSpecVerWindow ranks at a time (one window covers a chunk
+        // of ordinary content; a chunk of one-byte blocks takes five).
+        uint16_t* const sp = s_pos[wv];
+        for (uint32_t r0 = 0; r0 < m[u]; r0 += (uint32_t)kSpecVerWindow) {
+          const uint32_t span_ = min((uint32_t)kSpecVerWindow, m[u] - r0);
+          int rk0 = (int)(in0 - c0_) - (int)first[u] - (int)r0, rk1 = (int)(in1 - c1_) - (int)first[u] - (int)r0;
+          uint32_t m0 = w0[u], m1 = w1[u];
+          // both dwords of a lane in one loop: it runs for the fullest dword of the wave (4-5 starts where a
+          // macroblock's chroma blocks lie, 2 in luma), not for the sum of the two
+          while (__any((m0 | m1) != 0u)) {
+            if (m0) {
+              const int z = __builtin_clz(m0);  // bit 31 is the dword's first byte
+              if ((uint32_t)rk0 < span_) sp[rk0] = (uint16_t)(q0 + (uint32_t)z);
+              rk0++;
+              m0 &= ~(0x80000000u >> z);
+            }
+            if (m1) {
+              const int z = __builtin_clz(m1);
+              if ((uint32_t)rk1 < span_) sp[rk1] = (uint16_t)(q1 + (uint32_t)z);
+              rk1++;
+              m1 &= ~(0x80000000u >> z);
+            }
           }
-        }
-#pragma unroll
-        for (int u = 0; u < kSpecVerBatch; u++) {
-#pragma unroll
-          for (int t = 0; t < 4; t++) {
-            const uint32_t k = k0 + 64u * (uint32_t)t + (uint32_t)lane;
-            if (k < m[u]) out[base[u] + k] = start[u] + v[u][t];
-          }
+          // (one wave, and a wave's LDS operations complete in order: the reads below see the writes above; the
+          // compiler is told not to move them across)
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          for (uint32_t k = (uint32_t)lane; k < span_; k += 64u) o[r0 + k] = start[u] + (uint32_t)sp[k];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
       }
     }
@@ -438,10 +482,11 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
 __global__ __launch_bounds__(64) void k_spec_repair(const FrameDev* __restrict__ frames,
                                                      const SpecChunkDev* __restrict__ chunks,
                                                      const uint8_t* __restrict__ stream,
-                                                     const QTab* __restrict__ lut, uint16_t* __restrict__ records,
+                                                     const QTab* __restrict__ lut, uint32_t* __restrict__ recbits,
                                                      uint32_t* __restrict__ nrec, uint32_t* __restrict__ wstart,
                                                      uint2* __restrict__ hand, const uint2* __restrict__ fix,
                                                      const uint32_t* __restrict__ nfix) {
+  __shared__ uint32_t s_bits[kSpecTilesMax * 4];  // the re-walked span's start bits (at most kSpecSpan bytes)
   const uint32_t n = *nfix;
   for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
     const uint2 e = fix[i];
@@ -449,8 +494,13 @@ __global__ __launch_bounds__(64) void k_spec_repair(const FrameDev* __restrict__
     const FrameDev f = frames[sc.frame];
     const uint32_t limit = (sc.c + 1u) * (uint32_t)kSpecChunk;  // where the walker's span ends
     uint32_t take, tail;
-    const uint32_t cnt = walk_record(f, stream, lut, e.y, sc.c * (uint32_t)kSpecChunk, limit,
-                                     records + spec_rec_base(e.x), (uint32_t)kSpecCap, take, tail, e.x, kSpecRecInterleave);
+    for (int k = threadIdx.x; k < kSpecTilesMax * 4; k += 64) s_bits[k] = 0u;
+    __syncthreads();
+    const uint32_t cnt = walk_record(f, stream, lut, e.y, sc.c * (uint32_t)kSpecChunk, limit, s_bits,
+                                     (uint32_t)(kSpecTilesMax * 128), take, tail);
+    __syncthreads();
+    for (int k = threadIdx.x; k < kSpecTilesMax * 4; k += 64) recbits[spec_bits_dword(e.x, (uint32_t)k)] = s_bits[k];
+    __syncthreads();
     if (threadIdx.x == 0) {
       nrec[e.x] = cnt;
       wstart[e.x] = e.y;

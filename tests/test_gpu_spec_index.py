@@ -219,3 +219,41 @@ def test_content_that_locks_late_moves_the_plan_to_the_long_lead(monkeypatch):
     d.free(d_stream)
     d.free(d_out)
     d.close()
+
+
+def test_spans_of_one_byte_blocks_need_no_cap(dev):
+    """A still picture coded with key frames far apart is mostly 0xFF bytes: one block per byte.  Round 2's walkers
+    recorded 16-bit positions and refused a span with more than 2048 blocks (the packet then went to the exact
+    kernels); a start BIT per byte has no such limit: the packets are proven by the speculative index, and a chunk
+    of them runs through several windows of k_spec_verify's rank ordering (512 ranks each)."""
+    w, h = 1920, 1088
+    nblk = (w // 16) * (h // 16) * 6
+    enc = R.OracleEncoder(w, h, 255, 100, 16, 16)
+    still = R.synth_frame(w, h, 3, amp=8)
+    pkts = [enc.encode(still) for _ in range(3)]
+    assert (pkts[1][12:] == 255).mean() > 0.9 and pkts[1].size - 12 < nblk * 2  # nearly every block unchanged
+    # and an all-unchanged packet by hand, longer than a walker's chunk by far
+    total = 12 + nblk
+    hdr = np.array([total & 255, (total >> 8) & 255, (total >> 16) & 255, 0, 12, 0, w & 255, w >> 8, h & 255, h >> 8, 255, 0], np.uint8)
+    pkts.append(np.concatenate([hdr, np.full(nblk, 255, np.uint8)]))
+    d_stream, po, pl, hdrs = dev.upload_packets(pkts, align=1)
+    fsz = T.frame_bytes(w, h)
+    d_out = dev.alloc(fsz * len(pkts))
+    dev.memset(d_out, 0x41, fsz * len(pkts))
+    plan = dev.plan(hdrs, po, pl, np.arange(len(pkts), dtype=np.uint64) * np.uint64(fsz))
+    plan.decode(d_stream, d_out)
+    dev.sync()
+    want_idx = [R.OracleDecoder().block_offsets(p) - 12 for p in pkts]
+    got_idx = plan.read_index()
+    at = 0
+    for i, p in enumerate(pkts):
+        assert np.array_equal(got_idx[at:at + nblk + 1], want_idx[i][:nblk + 1]), i
+        at += nblk + 1
+        wantp = np.full(fsz, 0x41, np.uint8)  # every plan frame has its own picture: unchanged blocks keep the prefill
+        R.OracleDecoder().decode(p, wantp)
+        assert np.array_equal(dev.d2h(d_out, fsz, offset=i * fsz), wantp), i
+    proven, walkers = plan.spec_stats()
+    assert walkers > 0 and proven == len(pkts), (proven, walkers)
+    plan.close()
+    dev.free(d_stream)
+    dev.free(d_out)
