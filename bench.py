@@ -389,8 +389,10 @@ def main():
             "mpixels_per_s": round(fps * w * h / 1e6, 1),
             "median_step": {"device_ms": round(med, 4) if med else None,
                             "frames_per_s_per_gpu": round(n / (med * 1e-3), 1) if med else None,
-                            "note": "median over the timed steps of first-kernel-start to k_decode-end (HIP events, rank 0); "
-                                    "`value` is the contract's whole-run figure"},
+                            "note": "median over the timed steps of first-kernel-start to k_decode-end (HIP events, rank 0): the "
+                                    "LATENCY of a step.  Batch plans build the index of step k + 1 while step k is being "
+                                    "transformed (two block-offset indices per plan), so steps overlap and this is longer than "
+                                    "ms_per_step; `value` is the contract's whole-run figure"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "traffic_source": (f"profiles/traffic.json ({prof.get('note', '')})" if traffic is not None else

@@ -96,8 +96,19 @@ struct mi_rtj_plan {
   uint32_t* d_spec_state = nullptr;        // [2]: launches in a row that refused every packet, launches left paused
   int rotate = -1;                         // MI_RTJ_ROTATE: 1 / 0 = a k_decode wave takes all three parts of its groups / one part; -1 = by batch size
   const uint8_t* prev_pic = nullptr;       // sessions: where unchanged blocks of this launch are copied from
-  hipStream_t idx_stream = nullptr;        // sessions: the stream of the index kernels (not owned); null = the instance's
+  hipStream_t idx_stream = nullptr;        // the stream of the index kernels (sessions: theirs, not owned; batches: own_idx); null = the instance's
   hipEvent_t e_idx = nullptr;              // index done (only used with idx_stream)
+  // Batches: the index of launch k + 1 is built while launch k is still being transformed.  The only thing the two
+  // halves of a launch share is the block-offset index, so there are two of those (launches alternate) and an event per
+  // index that says "k_decode has read it" before the launch after next writes it again.  Both halves are bound by
+  // vector-instruction issue, so a long launch gains nothing; a short one (1024 pictures: 6 rounds of resident waves
+  // for k_decode, under one for the walkers) fills the other half's idle tails.  MI_RTJ_OVERLAP=0 / 1 overrides.
+  bool overlap = false;
+  hipStream_t own_idx = nullptr;
+  uint32_t* d_blkoff_b = nullptr;          // the second block-offset index (d_blkoff is the first)
+  hipEvent_t e_read[2] = {nullptr, nullptr};
+  int flip = 0;                            // which index the NEXT launch writes
+  int last = 0;                            // which one the last launch wrote (mi_rtj_plan_read_index)
   std::vector<Timed> ev[MI_RTJ_NUM_KERNELS];  // one pair per launch while profiling
   int launches = 0;
 };
@@ -360,6 +371,12 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
   // picture the unchanged blocks of i + 1 come from — is still being transformed.
   hipStream_t const ds = c->stream, is = p->idx_stream ? p->idx_stream : c->stream;
   hipStream_t cur = is;
+  uint32_t* const blk = p->overlap && p->flip ? p->d_blkoff_b : p->d_blkoff;  // the index this launch writes and reads
+  if (p->overlap) {
+    // the launch before last read this index: its k_decode must be through with it
+    if (p->e_read[p->flip]) HIPCHK(c, hipStreamWaitEvent(is, p->e_read[p->flip], 0));
+    else HIPCHK(c, hipEventCreateWithFlags(&p->e_read[p->flip], hipEventDisableTiming));
+  }
   Timed t[MI_RTJ_NUM_KERNELS];
   // while profiling: one event after every kernel; a kernel's start is its predecessor's end (they run back
   // to back on one stream), so a launch costs one event record per kernel instead of two
@@ -386,7 +403,7 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
   int rc;
   if (p->serial_index) {
     if ((rc = begin(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
-    hipLaunchKernelGGL(k_index_walk, dim3(p->n), dim3(64), 0, is, p->d_frames, st, c->d_lut, p->d_blkoff);
+    hipLaunchKernelGGL(k_index_walk, dim3(p->n), dim3(64), 0, is, p->d_frames, st, c->d_lut, blk);
     if ((rc = end(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
   } else {
     const uint32_t *todo = nullptr, *ntodo = nullptr;
@@ -423,12 +440,12 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
       // first pass; walkers that had not fallen into step are walked again from a known block start; second
       // pass over the packets concerned (both return at once when there is nothing to repair)
       hipLaunchKernelGGL(k_spec_verify, dim3(p->n), dim3(kSpecVerThreads), 0, is, p->d_frames, p->d_spec_base, c->d_lut,
-                         p->d_spec_rec, p->d_spec_nrec, p->d_blkoff, p->d_spec_ok, p->d_spec_todo + 1, p->d_spec_todo, state,
+                         p->d_spec_rec, p->d_spec_nrec, blk, p->d_spec_ok, p->d_spec_todo + 1, p->d_spec_todo, state,
                          p->d_spec_wstart, p->d_spec_hand, p->d_spec_fix, p->d_spec_nfix, 1);
       hipLaunchKernelGGL(k_spec_repair, dim3(kSpecRepairGrid), dim3(64), 0, is, p->d_frames, p->d_spec_chunks, st,
                          c->d_lut, p->d_spec_rec, p->d_spec_nrec, p->d_spec_wstart, p->d_spec_hand, p->d_spec_fix, p->d_spec_nfix);
       hipLaunchKernelGGL(k_spec_verify, dim3(p->n), dim3(kSpecVerThreads), 0, is, p->d_frames, p->d_spec_base, c->d_lut,
-                         p->d_spec_rec, p->d_spec_nrec, p->d_blkoff, p->d_spec_ok, p->d_spec_todo + 1, p->d_spec_todo, state,
+                         p->d_spec_rec, p->d_spec_nrec, blk, p->d_spec_ok, p->d_spec_todo + 1, p->d_spec_todo, state,
                          p->d_spec_wstart, p->d_spec_hand, p->d_spec_fix, p->d_spec_nfix, 2);
       if ((rc = end(MI_RTJ_K_SPEC_VERIFY)) != MI_RTJ_OK) return rc;
       if (state) hipLaunchKernelGGL(k_spec_policy, dim3(1), dim3(256), 0, is, (uint32_t)p->n, (uint32_t)p->n_spec, p->d_spec_todo, p->d_spec_nfix, state);
@@ -456,10 +473,10 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
     if ((rc = begin(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
     if (p->emit_walk)
       hipLaunchKernelGGL(k_index_emit_walk, dim3(p->max_chunks, p->n), dim3(64), 0, is, p->d_frames, st,
-                         c->d_lut, p->d_chunk_pos, p->d_chunk_mb, p->d_blkoff);
+                         c->d_lut, p->d_chunk_pos, p->d_chunk_mb, blk);
     else
       hipLaunchKernelGGL(k_index_emit, dim3(p->max_chunks, rows), dim3(kEmitThreads), 0, is, p->d_frames,
-                         p->d_lentab, p->d_chunk_pos, p->d_chunk_mb, p->d_blkoff, todo, ntodo);
+                         p->d_lentab, p->d_chunk_pos, p->d_chunk_mb, blk, todo, ntodo);
     if ((rc = end(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
   }
   if (is != ds) {  // k_decode waits for the index (and, through it, for the packet's copy in)
@@ -485,22 +502,27 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
     // fetched from the previous packet's picture); a launch runs the one that carries nothing else
     if (span == 3u) {
       if (p->prev_pic)
-        hipLaunchKernelGGL((k_decode<true, true>), grid, block, 0, ds, p->d_frames, st, c->d_lut, p->d_blkoff, out8,
+        hipLaunchKernelGGL((k_decode<true, true>), grid, block, 0, ds, p->d_frames, st, c->d_lut, blk, out8,
                            p->prev_pic);
       else
-        hipLaunchKernelGGL((k_decode<true, false>), grid, block, 0, ds, p->d_frames, st, c->d_lut, p->d_blkoff, out8,
+        hipLaunchKernelGGL((k_decode<true, false>), grid, block, 0, ds, p->d_frames, st, c->d_lut, blk, out8,
                            (const uint8_t*)nullptr);
     } else {
       if (p->prev_pic)
-        hipLaunchKernelGGL((k_decode<false, true>), grid, block, 0, ds, p->d_frames, st, c->d_lut, p->d_blkoff, out8,
+        hipLaunchKernelGGL((k_decode<false, true>), grid, block, 0, ds, p->d_frames, st, c->d_lut, blk, out8,
                            p->prev_pic);
       else
-        hipLaunchKernelGGL((k_decode<false, false>), grid, block, 0, ds, p->d_frames, st, c->d_lut, p->d_blkoff,
+        hipLaunchKernelGGL((k_decode<false, false>), grid, block, 0, ds, p->d_frames, st, c->d_lut, blk,
                            out8, (const uint8_t*)nullptr);
     }
   }
   if ((rc = end(MI_RTJ_K_DECODE)) != MI_RTJ_OK) return rc;
   HIPCHK(c, hipGetLastError());
+  if (p->overlap) {
+    HIPCHK(c, hipEventRecord(p->e_read[p->flip], ds));
+    p->last = p->flip;
+    p->flip ^= 1;
+  }
   p->launches++;
   return MI_RTJ_OK;
 }
@@ -709,7 +731,24 @@ hipMalloc((void**)&p->d_blkoff, sizeof(uint32_t) * p->n_index) != hipSuccess) {
     mi_rtj_plan_destroy(p);
     return nullptr;
   }
+  {
+    const char* ov = getenv("MI_RTJ_OVERLAP");
+    p->overlap = ov ? atoi(ov) != 0 : (uint64_t)p->n * p->max_groups >= (uint64_t)kDecRotateMinGroups;
+    if (p->overlap) {
+      if (hipMalloc((void**)&p->d_blkoff_b, sizeof(uint32_t) * p->n_index) != hipSuccess ||
+          hipStreamCreateWithFlags(&p->own_idx, hipStreamNonBlocking) != hipSuccess) {
+        fail(c, MI_RTJ_ERR_NOMEM, "second block index / index stream of the plan");
+        mi_rtj_plan_destroy(p);
+        return nullptr;
+      }
+      p->idx_stream = p->own_idx;
+    }
+  }
   if (plan_upload(p) != MI_RTJ_OK) {
+    mi_rtj_plan_destroy(p);
+    return nullptr;
+  }
+  if (p->overlap && hipStreamSynchronize(c->stream) != hipSuccess) {  // the descriptors are read from the other stream too
     mi_rtj_plan_destroy(p);
     return nullptr;
   }
@@ -739,6 +778,13 @@ void mi_rtj_plan_destroy(mi_rtj_plan* p) {
   if (p->d_spec_state) (void)hipFree(p->d_spec_state);
   if (p->d_spec_ok) (void)hipFree(p->d_spec_ok);
   if (p->e_idx) (void)hipEventDestroy(p->e_idx);
+  if (p->own_idx) {
+    (void)hipStreamSynchronize(p->own_idx);
+    (void)hipStreamDestroy(p->own_idx);
+  }
+  if (p->d_blkoff_b) (void)hipFree(p->d_blkoff_b);
+  for (hipEvent_t e : p->e_read)
+    if (e) (void)hipEventDestroy(e);
   delete p;
 }
 
@@ -848,7 +894,9 @@ int mi_rtj_plan_read_index(mi_rtj_plan* p, uint32_t* dst, size_t max_entries) {
   if (!p || !dst) return MI_RTJ_ERR_ARG;
   mi_rtj_ctx* c = p->ctx;
   std::vector<uint32_t> all(p->n_index);
-  HIPCHK(c, hipMemcpyAsync(all.data(), p->d_blkoff, sizeof(uint32_t) * p->n_index, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // (k_decode of the last launch waited for its index)
+  HIPCHK(c, hipMemcpyAsync(all.data(), p->overlap && p->last ? p->d_blkoff_b : p->d_blkoff, sizeof(uint32_t) * p->n_index,
+                           hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   size_t k = 0;
   for (int i = 0; i < p->n; i++) {

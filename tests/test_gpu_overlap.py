@@ -1,0 +1,62 @@
+"""Batch plans build the block-offset index of launch k + 1 while launch k is being transformed: two indices per plan,
+the index kernels on a stream of their own (csrc/mi_rtjpeg.hip, plan_launch).  MI_RTJ_OVERLAP=1 switches that on for
+plans of any size: launches queued back to back without a sync in between must each leave the oracle's pictures and
+the oracle's index, whichever of the two indices they used, with the exact and with the speculative index."""
+import numpy as np
+import pytest
+
+import rtjlib as R
+import test_gpu_parity as T
+from pkg import P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=["0", "1"], ids=["exact-index", "speculative-index"])
+def dev(monkeypatch, request):
+    monkeypatch.setenv("MI_RTJ_OVERLAP", "1")
+    monkeypatch.setenv("MI_RTJ_SPEC", request.param)
+    d = P.MiRtj()
+    yield d
+    d.close()
+
+
+def test_back_to_back_launches(dev):
+    w, h = 640, 368
+    pkts = [R.OracleEncoder(w, h, Q).encode(R.synth_frame(w, h, i, seed=31, amp=a))
+            for i, (Q, a) in enumerate([(255, 8), (128, 30), (200, 0), (255, 64), (60, 12)])]
+    fsz = T.frame_bytes(w, h)
+    want = []
+    for p in pkts:
+        o = np.zeros(fsz, np.uint8)
+        R.OracleDecoder().decode(p, o)
+        want.append(o)
+    d_stream, po, pl, hdrs = dev.upload_packets(pkts, align=1)
+    outs = [dev.alloc(fsz * len(pkts)) for _ in range(5)]
+    plan = dev.plan(hdrs, po, pl, np.arange(len(pkts), dtype=np.uint64) * np.uint64(fsz))
+    for d_out in outs:  # five launches in a row, no sync: indices 0 1 0 1 0
+        plan.decode(d_stream, d_out)
+    dev.sync()
+    for k, d_out in enumerate(outs):
+        for i in range(len(pkts)):
+            assert np.array_equal(dev.d2h(d_out, fsz, offset=i * fsz), want[i]), (k, i)
+    nblk = (w // 16) * (h // 16) * 6
+    for extra in range(2):  # the index the LAST launch wrote is the one read back: after 5 and after 6 launches
+        idx = plan.read_index()
+        at = 0
+        for i, p in enumerate(pkts):
+            assert np.array_equal(idx[at:at + nblk + 1], R.OracleDecoder().block_offsets(p) - 12), (extra, i)
+            at += nblk + 1
+        plan.decode(d_stream, outs[0])
+    dev.sync()
+    plan.close()
+    dev.free(d_stream)
+    for d_out in outs:
+        dev.free(d_out)
+
+
+def test_parity_suite_with_overlapped_plans(dev):
+    T.test_mixed_batch_sizes_and_qualities(dev)
+    T.test_skip_blocks_leave_destination_untouched_in_batches(dev)
+    T.test_truncated_and_empty_packets(dev)
+    T.test_chunk_boundaries_and_long_blocks(dev)

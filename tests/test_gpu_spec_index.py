@@ -225,16 +225,20 @@ def test_spans_of_one_byte_blocks_need_no_cap(dev):
     """A still picture coded with key frames far apart is mostly 0xFF bytes: one block per byte.  Round 2's walkers
     recorded 16-bit positions and refused a span with more than 2048 blocks (the packet then went to the exact
     kernels); a start BIT per byte has no such limit: the packets are proven by the speculative index, and a chunk
-    of them runs through several windows of k_spec_verify's rank ordering (512 ranks each)."""
-    w, h = 1920, 1088
+    of them runs through several windows of k_spec_verify's rank ordering (512 ranks each).
+    (Quality 128: luma and chroma blocks parse alike there, so a walker is in step as soon as it stands on a block
+    start.  At a quality where they differ, walkers in a run of one-byte blocks keep whatever macroblock phase they
+    assumed — every block is one byte whatever its type — and such packets go to the exact kernels, by design.)"""
+    w, h, Q = 1920, 1088, 128
+    assert R.oracle_tables(Q)[2] == R.oracle_tables(Q)[3]
     nblk = (w // 16) * (h // 16) * 6
-    enc = R.OracleEncoder(w, h, 255, 100, 16, 16)
+    enc = R.OracleEncoder(w, h, Q, 100, 16, 16)
     still = R.synth_frame(w, h, 3, amp=8)
     pkts = [enc.encode(still) for _ in range(3)]
     assert (pkts[1][12:] == 255).mean() > 0.9 and pkts[1].size - 12 < nblk * 2  # nearly every block unchanged
     # and an all-unchanged packet by hand, longer than a walker's chunk by far
     total = 12 + nblk
-    hdr = np.array([total & 255, (total >> 8) & 255, (total >> 16) & 255, 0, 12, 0, w & 255, w >> 8, h & 255, h >> 8, 255, 0], np.uint8)
+    hdr = np.array([total & 255, (total >> 8) & 255, (total >> 16) & 255, 0, 12, 0, w & 255, w >> 8, h & 255, h >> 8, Q, 0], np.uint8)
     pkts.append(np.concatenate([hdr, np.full(nblk, 255, np.uint8)]))
     d_stream, po, pl, hdrs = dev.upload_packets(pkts, align=1)
     fsz = T.frame_bytes(w, h)
