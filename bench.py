@@ -474,6 +474,7 @@ def main():
                 continue
             sw = run_frames(a, dev, rank, nb, a.amp, 3, 2, barrier, sync_all)
             sweep[str(nb)] = {"frames_per_s": round(nb * 3 / sw["dt"], 1),
+                              "steps_overlap": 129 <= nb < 8192 and w * h == 1920 * 1088,  # mi_rtjpeg.hip: plan overlap policy
                               "kernels_ms": {k: round(v / max(sw["launches"], 1), 4) for k, v in sw["ktimes"].items() if v > 0},
                               "index": "speculative" if sw["plan"].spec_stats()[1] else "exact"}
             sw["plan"].close()
@@ -482,7 +483,9 @@ def main():
         sweep[str(n)] = {"frames_per_s": out["value"], "kernels_ms": {k: v["ms"] for k, v in out["kernels"].items()},
                          "index": "speculative" if out["speculative_index"]["stream_chunks"] else "exact"}
         out["by_batch"] = dict(sweep, note="frames per launch -> whole-step frames/s (3 timed steps, 2 warm-up; the last "
-                                           "entry is the headline run)")
+                                           "entry is the headline run).  steps_overlap: plans of that size build the index of "
+                                           "step k + 1 while step k is transformed; their kernels share the device, so kernels_ms "
+                                           "of those entries are not kernel costs (the headline's are: its kernels run back to back)")
 
     # SURVEY.md section 8d's stress variant (noise +-64: 2.3 MB packets, nothing for the speculative index to lock on)
     # as a second, short, clearly labelled measurement; never part of `value`

@@ -29,6 +29,7 @@ namespace {
 
 constexpr size_t kAllocPad = 256;  // kernels may read a few bytes past a packet's last dword
 constexpr int kMaxPlanFrames = 65535;       // a plan's frames are the y dimension of every grid
+constexpr uint64_t kOverlapMaxGroups = 8192ull * 255ull;  // plans from this many macroblock groups on run their kernels back to back
 
 std::mutex g_err_mu;
 std::string g_create_err = "";
@@ -733,7 +734,12 @@ hipMalloc((void**)&p->d_blkoff, sizeof(uint32_t) * p->n_index) != hipSuccess) {
   }
   {
     const char* ov = getenv("MI_RTJ_OVERLAP");
-    p->overlap = ov ? atoi(ov) != 0 : (uint64_t)p->n * p->max_groups >= (uint64_t)kDecRotateMinGroups;
+    // by default for plans of 129 .. 8191 pictures of 1080p: smaller ones do not fill the device either way and pay for
+    // the cross-stream waits; longer launches gain under 1 % (profiles/r03/ab_overlap_index_with_transform.txt), and
+    // kernels that share the device cannot be timed one by one — the per-kernel figures of bench.py and rocprofv3 are
+    // taken on launches that run their kernels back to back
+    const uint64_t groups = (uint64_t)p->n * p->max_groups;
+    p->overlap = ov ? atoi(ov) != 0 : groups >= (uint64_t)kDecRotateMinGroups && groups < (uint64_t)kOverlapMaxGroups;
     if (p->overlap) {
       if (hipMalloc((void**)&p->d_blkoff_b, sizeof(uint32_t) * p->n_index) != hipSuccess ||
           hipStreamCreateWithFlags(&p->own_idx, hipStreamNonBlocking) != hipSuccess) {

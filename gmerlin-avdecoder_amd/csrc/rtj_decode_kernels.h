@@ -412,7 +412,7 @@ __host__ __device__ constexpr uint32_t decode_slots(uint32_t groups, uint32_t fr
   if (by_batch > groups) by_batch = groups;
   return (by_iters > by_batch ? by_iters : by_batch) | 1u;
 }
-constexpr uint32_t kDecRotateMinGroups = 65536;  // groups in a batch from which a wave takes all three parts (span 3)
+constexpr uint32_t kDecRotateMinGroups = 32768;  // groups in a batch from which a wave takes all three parts (span 3): 129 pictures of 1080p
 constexpr uint32_t kFetchSpan = 72;             // a block's loads stay below its start + this (64 + alignment + look-ahead)
 
 // ---------------------------------------------------------------------------------------

@@ -401,6 +401,8 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
     // chunk's blocks.  A wave works on kSpecVerBatch chunks at a time so that it waits for memory once per batch.
     constexpr uint32_t kWaves = kSpecVerThreads / 64;
     static_assert(kSpecTilesMax * 4 <= 128, "two dwords of start bits per lane");
+    // (a wave taking kSpecVerBatch NEIGHBOURING chunks, whose walkers' bits share lines, measured the same:
+    // profiles/r03/ab_verify_adjacent_chunks.txt)
     for (uint32_t j0 = (uint32_t)wv; j0 < tile_n; j0 += kSpecVerBatch * kWaves) {
       uint32_t base[kSpecVerBatch], m[kSpecVerBatch], start[kSpecVerBatch], first[kSpecVerBatch];
       uint32_t w0[kSpecVerBatch], w1[kSpecVerBatch];
