@@ -660,7 +660,13 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
 
     const bool live_blk = live_any;  // the lanes of this iteration's transform round
 
+    // (-DMIRTJ_EXP_NO_PARSE / -DMIRTJ_EXP_NO_TRANSFORM: census builds for the instruction budget of DESIGN.md section 8 —
+    // wrong pictures, counted with rocprofv3 --pmc SQ_INSTS_VALU, never shipped)
+#ifdef MIRTJ_EXP_NO_PARSE
+    if (false) {
+#else
     if (live_blk) {
+#endif
       // ---- stream -> dequantised coefficients, int16, transposed (lib/RTjpeg.c:157-186) ----
       // The block's bytes are consumed 16 at a time from registers (aligned dwords + a byte funnel
       // shift), eight to a half round so that short blocks stop early.  The only loop-carried value
@@ -847,6 +853,11 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
         put_packed(o);
       };
 
+#ifdef MIRTJ_EXP_NO_TRANSFORM
+      if (true) {
+        for (int r = 0; r < kRowStores; r++) put_packed(make_uint2(0u, 0u));
+      } else
+#endif
       if (lo) {
         // rows 0-3 of the column pairs (0, 1) and (2, 3)
         const uint4 qa = my[0], qb = my[2];
@@ -950,6 +961,10 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
 #pragma unroll
         for (int i = 0; i < 8; i++) q[i] = my[i];
         packed = __all(pk_range_full(q, KP));  // wave-uniform
+#ifdef MIRTJ_EXP_PK_ONLY
+        packed = true;  // census builds have no other path: a wave that stored nothing would break the counted wait below
+                        // (profiles/r03/faults/: exactly that happened with an unparsed scratch)
+#endif
         MIRTJ_STAMP(5);  // coordinates, scratch reads, 16-bit range test
         if (packed) {
           // ---- column pass on the four column pairs, as they lie in the scratch (rtj_idct_pk.h) ----

@@ -5,7 +5,7 @@ set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc
 mkdir -p $OUT
-ARGS="${@:---steps 3 --warmup 1 --no-cpu --no-stress --no-e2e}"
+ARGS="${@:---steps 3 --warmup 1 --no-cpu --no-stress --no-e2e --no-sweep}"
 run() { # name counters...
   local name=$1; shift
   timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py $ARGS > $OUT/$name.log 2>&1
