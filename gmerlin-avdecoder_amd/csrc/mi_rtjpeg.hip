@@ -90,6 +90,7 @@ struct mi_rtj_plan {
   uint32_t* d_spec_wstart = nullptr;       // [walkers]: first byte each walker parsed (repairs move it)
   uint2* d_spec_hand = nullptr;            // [walkers]: where a chunk takes over / where the next one has to
   uint2* d_spec_fix = nullptr;             // [walkers]: (walker, byte to start from) of the chunks to walk again
+  uint8_t* d_spec_flag = nullptr;          // [walkers + 64]: 1 = on that list in this launch
   uint32_t* d_spec_nfix = nullptr;
   uint32_t* d_spec_ok = nullptr;           // [n]: 1 = the packet's index is proven
   uint32_t* d_spec_todo = nullptr;         // [n + 1]: count, then the packets left to the exact kernels
@@ -312,10 +313,13 @@ int plan_alloc_chunks(mi_rtj_plan* p) {
         (void)hipFree(p->d_spec_wstart);
         (void)hipFree(p->d_spec_hand);
         (void)hipFree(p->d_spec_fix);
+        (void)hipFree(p->d_spec_flag);
         p->d_spec_chunks = nullptr;
         p->d_spec_rec = nullptr;
         p->d_spec_nrec = p->d_spec_wstart = nullptr;
-        p->d_spec_hand = p->d_spec_fix = nullptr;
+        p->d_spec_hand = nullptr;
+        p->d_spec_fix = nullptr;
+        p->d_spec_flag = nullptr;
         p->cap_spec = 0;  // a failed hipMalloc below must not leave freed pointers behind
       }
       HIPCHK(c, hipMalloc((void**)&p->d_spec_chunks, sizeof(SpecChunkDev) * p->n_spec));
@@ -324,6 +328,7 @@ int plan_alloc_chunks(mi_rtj_plan* p) {
       HIPCHK(c, hipMalloc((void**)&p->d_spec_wstart, sizeof(uint32_t) * p->n_spec));
       HIPCHK(c, hipMalloc((void**)&p->d_spec_hand, sizeof(uint2) * p->n_spec));
       HIPCHK(c, hipMalloc((void**)&p->d_spec_fix, sizeof(uint2) * p->n_spec));
+      HIPCHK(c, hipMalloc((void**)&p->d_spec_flag, p->n_spec + 64));
       if (!p->d_spec_nfix) {
         HIPCHK(c, hipMalloc((void**)&p->d_spec_nfix, sizeof(uint32_t)));
         HIPCHK(c, hipMemsetAsync(p->d_spec_nfix, 0, sizeof(uint32_t), c->stream));
@@ -413,7 +418,7 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
     // noisy content defeats the speculation; a plan that sees every packet refused twice in a row goes
     // without it for kSpecPauseLaunches launches.  The policy lives on the device (k_spec_policy), so it
     // also works when launches are queued faster than they run.
-    const bool no_policy = p->spec_mode == 1 || p->spec_mode == 3;  // always speculate: short (1) or long (3) lead
+    const bool no_policy = p->spec_mode == 1 || p->spec_mode == 3 || p->spec_mode == 4;  // always speculate: short (1), long (3) or very long (4) lead
     uint32_t* const state = no_policy ? nullptr : p->d_spec_state;
     if (spec) {
       ntodo = p->d_spec_todo;
@@ -421,6 +426,7 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
       rows = std::min<unsigned>(rows, kSpecFallbackRows);
       HIPCHK(c, hipMemsetAsync(p->d_spec_todo, 0, sizeof(uint32_t), is));
       HIPCHK(c, hipMemsetAsync(p->d_spec_nfix, 0, sizeof(uint32_t), is));
+      HIPCHK(c, hipMemsetAsync(p->d_spec_flag, 0, p->n_spec + 64, is));
       if ((rc = begin(MI_RTJ_K_SPEC_WALK)) != MI_RTJ_OK) return rc;
       // both walker forms (short and long lead) are queued; the one the policy state does not name returns at once
       const dim3 wgrid((unsigned)((p->n_spec + 63) / 64));
@@ -428,12 +434,16 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
   hipLaunchKernelGGL((k_spec_walk<PHASE, LEAD>), wgrid, dim3(64), 0, is, p->d_frames, p->d_spec_chunks,         \
                      (uint32_t)p->n_spec, st, c->d_lut, p->d_spec_rec, p->d_spec_nrec, p->d_spec_wstart, p->d_spec_hand, \
                      state)
+      // with the policy (state) all three forms are queued and the two it does not name return at once; without it
+      // (MI_RTJ_SPEC = 1 / 3 / 4: tests) only the form asked for
       if (p->one_block_type) {
-        if (p->spec_mode != 3) MIRTJ_LAUNCH_WALK(false, kSpecLead);
+        if (state || p->spec_mode == 1) MIRTJ_LAUNCH_WALK(false, kSpecLead);
         if (state || p->spec_mode == 3) MIRTJ_LAUNCH_WALK(false, kSpecLeadLong);
+        if (state || p->spec_mode == 4) MIRTJ_LAUNCH_WALK(false, kSpecLeadVery);
       } else {
-        if (p->spec_mode != 3) MIRTJ_LAUNCH_WALK(true, kSpecLead);
+        if (state || p->spec_mode == 1) MIRTJ_LAUNCH_WALK(true, kSpecLead);
         if (state || p->spec_mode == 3) MIRTJ_LAUNCH_WALK(true, kSpecLeadLong);
+        if (state || p->spec_mode == 4) MIRTJ_LAUNCH_WALK(true, kSpecLeadVery);
       }
 #undef MIRTJ_LAUNCH_WALK
       if ((rc = end(MI_RTJ_K_SPEC_WALK)) != MI_RTJ_OK) return rc;
@@ -442,12 +452,13 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
       // pass over the packets concerned (both return at once when there is nothing to repair)
       hipLaunchKernelGGL(k_spec_verify, dim3(p->n), dim3(kSpecVerThreads), 0, is, p->d_frames, p->d_spec_base, c->d_lut,
                          p->d_spec_rec, p->d_spec_nrec, blk, p->d_spec_ok, p->d_spec_todo + 1, p->d_spec_todo, state,
-                         p->d_spec_wstart, p->d_spec_hand, p->d_spec_fix, p->d_spec_nfix, 1);
+                         p->d_spec_wstart, p->d_spec_hand, p->d_spec_fix, p->d_spec_nfix, p->d_spec_flag, 1);
       hipLaunchKernelGGL(k_spec_repair, dim3(kSpecRepairGrid), dim3(64), 0, is, p->d_frames, p->d_spec_chunks, st,
-                         c->d_lut, p->d_spec_rec, p->d_spec_nrec, p->d_spec_wstart, p->d_spec_hand, p->d_spec_fix, p->d_spec_nfix);
+                         c->d_lut, p->d_spec_rec, p->d_spec_nrec, p->d_spec_wstart, p->d_spec_hand, p->d_spec_fix, p->d_spec_nfix,
+                         p->d_spec_flag, (uint32_t)p->n_spec);
       hipLaunchKernelGGL(k_spec_verify, dim3(p->n), dim3(kSpecVerThreads), 0, is, p->d_frames, p->d_spec_base, c->d_lut,
                          p->d_spec_rec, p->d_spec_nrec, blk, p->d_spec_ok, p->d_spec_todo + 1, p->d_spec_todo, state,
-                         p->d_spec_wstart, p->d_spec_hand, p->d_spec_fix, p->d_spec_nfix, 2);
+                         p->d_spec_wstart, p->d_spec_hand, p->d_spec_fix, p->d_spec_nfix, p->d_spec_flag, 2);
       if ((rc = end(MI_RTJ_K_SPEC_VERIFY)) != MI_RTJ_OK) return rc;
       if (state) hipLaunchKernelGGL(k_spec_policy, dim3(1), dim3(256), 0, is, (uint32_t)p->n, (uint32_t)p->n_spec, p->d_spec_todo, p->d_spec_nfix, state);
     }
@@ -779,6 +790,7 @@ void mi_rtj_plan_destroy(mi_rtj_plan* p) {
   if (p->d_spec_wstart) (void)hipFree(p->d_spec_wstart);
   if (p->d_spec_hand) (void)hipFree(p->d_spec_hand);
   if (p->d_spec_fix) (void)hipFree(p->d_spec_fix);
+  if (p->d_spec_flag) (void)hipFree(p->d_spec_flag);
   if (p->d_spec_nfix) (void)hipFree(p->d_spec_nfix);
   if (p->d_spec_todo) (void)hipFree(p->d_spec_todo);
   if (p->d_spec_state) (void)hipFree(p->d_spec_state);
@@ -856,13 +868,13 @@ int mi_rtj_plan_spec_lead(mi_rtj_plan* p, int* lead_bytes, int* paused_launches)
   *lead_bytes = 0;
   *paused_launches = 0;
   if (!p->spec) return MI_RTJ_OK;
-  *lead_bytes = p->spec_mode == 3 ? kSpecLeadLong : kSpecLead;
-  if (p->spec_mode == 1 || p->spec_mode == 3 || !p->d_spec_state) return MI_RTJ_OK;  // no policy
+  *lead_bytes = p->spec_mode == 4 ? kSpecLeadVery : p->spec_mode == 3 ? kSpecLeadLong : kSpecLead;
+  if (p->spec_mode == 1 || p->spec_mode == 3 || p->spec_mode == 4 || !p->d_spec_state) return MI_RTJ_OK;  // no policy
   uint32_t st[kSpecStWords];
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemcpyAsync(st, p->d_spec_state, sizeof(st), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  *lead_bytes = st[kSpecStLong] ? kSpecLeadLong : kSpecLead;
+  *lead_bytes = spec_lead_of_level(st[kSpecStLong]);
   *paused_launches = (int)st[kSpecStPause];
   return MI_RTJ_OK;
 }

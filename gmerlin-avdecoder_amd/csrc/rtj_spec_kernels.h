@@ -47,7 +47,20 @@ constexpr int kSpecLead = MIRTJ_SPEC_LEAD;   // bytes it parses before them, fro
 #define MIRTJ_SPEC_LEAD_LONG 1536
 #endif
 constexpr int kSpecLeadLong = MIRTJ_SPEC_LEAD_LONG;  // the lead of the second walker form, for content that falls into step late
-constexpr int kSpecSpan = kSpecLeadLong + kSpecChunk;  // the longest span a walker parses
+#ifndef MIRTJ_SPEC_LEAD_VERY
+#define MIRTJ_SPEC_LEAD_VERY 6144
+#endif
+// The third form: three chunks of lead.  Content with noise of +-32 at the highest quality (blocks of 32 bytes, few
+// zero runs) needs it: half of the walks that start at an arbitrary byte are in step after 1.2 KB, 99 % after 5 KB
+// (tools/analysis/lock_distance.py).  A walker then parses four times its chunk, still a third of what the exact index
+// costs.  Walkers of a packet's first chunks, whose lead would start before the packet, start at byte 0 — on the true
+// chain — with whatever lead that leaves them.
+constexpr int kSpecLeadVery = MIRTJ_SPEC_LEAD_VERY;
+constexpr int kSpecSpan = kSpecLeadVery + kSpecChunk;  // the longest span a walker parses
+// which lead a plan's walkers use: the value of the policy's state word kSpecStLong
+__host__ __device__ constexpr int spec_lead_of_level(uint32_t level) {
+  return level == 0u ? kSpecLead : level == 1u ? kSpecLeadLong : kSpecLeadVery;
+}
 constexpr int kSpecTile = 128;    // bytes per lane fetched at a time (one cache line)
 // What a walker records: one START BIT per byte of its span — bit (31 - i) of dword k says that a block starts at
 // walker-relative position 32 k + i (the walker's first byte is taken to start one).  The walker shifts the "previous
@@ -70,8 +83,9 @@ constexpr int kSpecRingRow = 64 + 16;       // LDS bytes per lane: the start bit
                                             // stream: more than a macroblock, 384) + bank padding
 static_assert(kSpecSpan % kSpecTile == 0 && kSpecSpan < 65536, "walker span: whole tiles, 16-bit positions");
 static_assert(kSpecLead >= 6 * 64 + 64 && kSpecLead % kSpecTile == 0 && kSpecChunk % kSpecTile == 0, "the lead: at least one whole macroblock, whole tiles");
-static_assert(kSpecLeadLong >= kSpecLead && kSpecLeadLong % kSpecTile == 0 && kSpecLeadLong <= kSpecChunk,
-              "a walker starts inside the chunk before its own (chunk 1's walker at byte kSpecChunk - lead >= 0)");
+static_assert(kSpecLeadLong >= kSpecLead && kSpecLeadLong % kSpecTile == 0 && kSpecLeadVery >= kSpecLeadLong &&
+                  kSpecLeadVery % kSpecTile == 0 && kSpecLeadVery % kSpecChunk == 0,
+              "leads: whole tiles, growing; the longest a whole number of chunks (a walker that cannot have it starts at byte 0)");
 
 struct SpecChunkDev {
   uint32_t frame;  // index into the plan's frames
@@ -159,7 +173,7 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
                                                    uint32_t* __restrict__ nrec, uint32_t* __restrict__ wstart,
                                                    uint2* __restrict__ hand, const uint32_t* __restrict__ state) {
   // both forms are launched; the plan's policy state says which one works (none while paused, k_spec_policy)
-  if (state && (state[kSpecStPause] || (state[kSpecStLong] != 0u) != (LEAD != kSpecLead))) return;
+  if (state && (state[kSpecStPause] || spec_lead_of_level(state[kSpecStLong]) != LEAD)) return;
   constexpr int kSpan = LEAD + kSpecChunk;
   static_assert(kSpan % kSpecTile == 0 && kSpan < 65536, "walker span: whole tiles, 16-bit positions");
   __shared__ __attribute__((aligned(16))) uint8_t s_ring[64 * kSpecRingRow];
@@ -169,7 +183,12 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
   const SpecChunkDev sc = chunks[act ? g : total - 1u];  // idle lanes shadow the last chunk and store nothing
   const FrameDev f = frames[sc.frame];
   const int lb = lut[f.qidx].lb8 + 1, cb = lut[f.qidx].cb8 + 1;  // DC + raw bytes of a luma / chroma block
-  const uint32_t start = sc.c ? sc.c * (uint32_t)kSpecChunk - (uint32_t)LEAD : 0u;  // first byte parsed
+  // first byte parsed: LEAD bytes before the chunk, or the packet's first byte where the packet does not reach that
+  // far back (then the walker is on the true chain from its first byte)
+  const uint32_t cstart = sc.c * (uint32_t)kSpecChunk;
+  const uint32_t start = cstart > (uint32_t)LEAD ? cstart - (uint32_t)LEAD : 0u;
+  const int take_tile = (int)((cstart - start) / (uint32_t)kSpecTile);  // the tile the walker's own chunk begins with
+  const int end_tile = take_tile + kSpecChunk / kSpecTile;             // ... and the first tile past it
   const uint8_t* gp = stream + f.data_off + start;
   const uint32_t sh = (uint32_t)((uintptr_t)gp & 3u);
   const uint32_t* g4 = (const uint32_t*)(gp - sh);
@@ -239,7 +258,8 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
     return 0u;  // nothing but the walker's own first byte (record 0, position 0)
   };
   uint32_t take = 0;  // where this walker's chunk takes over from its predecessor (chunk 0: byte 0, record 0)
-  uint32_t tail0 = 0;
+  uint32_t tail = 0;  // where the next chunk has to take over: the last unit start below the end of this one
+  uint32_t cnt_end = 0;  // block starts below the end of the walker's chunk
   uint32_t* const out_bits = recbits + spec_bits_dword(gw, 0);
   uint4 tb = make_uint4(0, 0, 0, 0);  // the tile's start bits
 
@@ -247,11 +267,15 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
   for (int t = 0; t < kSpan / kSpecTile; t++) {
     // the tile is parsed out of registers (fully unrolled: 128 byte steps); staging it in LDS for a
     // smaller loop body capped the kernel at 11 waves per CU
-    if (t == LEAD / kSpecTile) {  // the chunk begins with this tile
+    // the two hand-over points, per lane (walkers that started at byte 0 reach theirs earlier than the others)
+    if (__any(t == take_tile || t == end_tile)) {
       const uint32_t v = last_aligned_below(t);
-      take = sc.c ? v : 0u;
+      if (t == take_tile) take = sc.c ? v : 0u;
+      if (t == end_tile) {
+        tail = v;
+        cnt_end = cnt;
+      }
     }
-    if (t == kSpecChunk / kSpecTile) tail0 = last_aligned_below(t);  // chunk 0 (no lead) ends here
     uint32_t cur[33];
 #pragma unroll
     for (int k = 0; k < 33; k++) cur[k] = buf[k];
@@ -308,11 +332,14 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
                       __builtin_popcount(bw[3]));
   }
   *(uint4*)(out_bits + (size_t)(kSpan / kSpecTile - 1) * 256u) = tb;
+  if (end_tile == kSpan / kSpecTile) {  // (walkers with the whole lead end with the loop)
+    tail = last_aligned_below(kSpan / kSpecTile);
+    cnt_end = cnt;
+  }
   if (act) {
-    nrec[g] = cnt;
+    nrec[g] = cnt_end;  // block starts the walker saw up to the end of its chunk
     wstart[g] = start;
-    const uint32_t tail = last_aligned_below(kSpan / kSpecTile);
-    hand[g] = make_uint2(take, sc.c ? tail : tail0);  // .y: what the next chunk must take over from
+    hand[g] = make_uint2(take, tail);  // .y: what the next chunk must take over from
   }
 }
 
@@ -328,7 +355,7 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
                                                       uint32_t* __restrict__ ntodo, const uint32_t* __restrict__ state,
                                                       const uint32_t* __restrict__ wstart,
                                                       const uint2* __restrict__ hand, uint2* __restrict__ fix,
-                                                      uint32_t* __restrict__ nfix, int pass) {
+                                                      uint32_t* __restrict__ nfix, uint8_t* __restrict__ fixflag, int pass) {
   if (state && state[kSpecStPause]) {  // paused (k_spec_policy): nothing was walked, nothing is proven
     if (threadIdx.x == 0) ok[blockIdx.x] = 0;
     return;
@@ -371,6 +398,7 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
             // (macro)block start this one saw, and the packet gets a second pass
             soft = 1;
             fix[atomicAdd(nfix, 1u)] = make_uint2(sc0 + c + 1u, t);
+            fixflag[sc0 + c + 1u] = 1;  // (k_spec_repair: walkers to repair that follow one another are one wave's job)
           } else {
             bad = 1;
           }
@@ -386,7 +414,7 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
     __syncthreads();
     uint32_t before = s_carry[1] + incl - cnt;
     for (int k = 0; k < wv; k++) before += s_wave[k];
-    s_i0[tid] = i0;
+    s_i0[tid] = c < nsc && c ? hand[sc0 + c].x & 0xFFFFu : 0u;  // where the chunk's first block starts, walker-relative
     s_base[tid] = before;
     s_cnt[tid] = cnt;
     __syncthreads();
@@ -396,11 +424,13 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
     // counts of refused chunks are 0, everything is clipped to the packet's own index, and the exact
     // kernels rewrite it)
     const uint32_t tile_n = min((uint32_t)kSpecVerThreads, nsc - c0);
-    // A chunk's block starts are bits in its walker's record: at most kSpecTilesMax * 4 = 112 dwords, two per lane.
-    // Rank of a bit = starts before it (popcounts, one wave scan per half); the ranks first .. first + m - 1 are this
-    // chunk's blocks.  A wave works on kSpecVerBatch chunks at a time so that it waits for memory once per batch.
+    // A chunk's block starts are bits in its walker's record, from the hand-over point (at most a macroblock, 384
+    // bytes, before the chunk) to the end of the chunk: at most 77 dwords whatever the walker's lead, two per lane.
+    // Rank of a bit = starts between the hand-over point and it (popcounts, one wave scan per half); the ranks
+    // 0 .. m - 1 are this chunk's blocks.  A wave works on kSpecVerBatch chunks at a time so that it waits for memory
+    // once per batch.
     constexpr uint32_t kWaves = kSpecVerThreads / 64;
-    static_assert(kSpecTilesMax * 4 <= 128, "two dwords of start bits per lane");
+    static_assert((kSpecChunk + kEntries) / 32 + 2 <= 128, "two dwords of start bits per lane");
     // (a wave taking kSpecVerBatch NEIGHBOURING chunks, whose walkers' bits share lines, measured the same:
     // profiles/r03/ab_verify_adjacent_chunks.txt)
     for (uint32_t j0 = (uint32_t)wv; j0 < tile_n; j0 += kSpecVerBatch * kWaves) {
@@ -415,8 +445,10 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
         start[u] = wstart[sc0 + c0 + j];
         first[u] = s_i0[j];
         const uint32_t R = sc0 + c0 + j;  // the walker whose starts are copied
-        w0[u] = m[u] ? recbits[spec_bits_dword(R, (uint32_t)lane)] : 0u;
-        w1[u] = m[u] && lane + 64 < kSpecTilesMax * 4 ? recbits[spec_bits_dword(R, (uint32_t)lane + 64u)] : 0u;
+        const uint32_t k0 = (first[u] >> 5) + (uint32_t)lane, k1 = k0 + 64u;  // dwords from the hand-over point on
+        w0[u] = m[u] && k0 < (uint32_t)(kSpecTilesMax * 4) ? recbits[spec_bits_dword(R, k0)] : 0u;
+        w1[u] = m[u] && k1 < (uint32_t)(kSpecTilesMax * 4) ? recbits[spec_bits_dword(R, k1)] : 0u;
+        if (lane == 0) w0[u] &= 0xFFFFFFFFu >> (first[u] & 31u);  // starts before the hand-over point (bit 31 = first byte)
       }
 #pragma unroll
       for (int u = 0; u < kSpecVerBatch; u++) {
@@ -425,9 +457,8 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
         const uint32_t in0 = wave_incl_scan(c0_);
         const uint32_t tot0 = (uint32_t)__builtin_amdgcn_readlane((int)in0, 63);
         const uint32_t in1 = wave_incl_scan(c1_) + tot0;
-        // rank relative to the chunk's first block (negative: a start of the lead, before the hand-over point)
         uint32_t* const o = out + base[u];
-        const uint32_t q0 = 32u * (uint32_t)lane, q1 = q0 + 2048u;  // walker-relative position of the dwords' first byte
+        const uint32_t q0 = (first[u] & ~31u) + 32u * (uint32_t)lane, q1 = q0 + 2048u;  // walker-relative position of the dwords' first byte
         // Ranks are scattered over the lanes (a lane owns the starts of its 32 bytes), the index wants them in order:
         // written straight to memory, a store instruction touched a dozen 64-byte pieces for 64 offsets and the kernel
         // took 2.1 ms per 16384 pictures.  The offsets are therefore put in rank order in LDS (scattered 16-bit writes
@@ -436,7 +467,7 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
         uint16_t* const sp = s_pos[wv];
         for (uint32_t r0 = 0; r0 < m[u]; r0 += (uint32_t)kSpecVerWindow) {
           const uint32_t span_ = min((uint32_t)kSpecVerWindow, m[u] - r0);
-          int rk0 = (int)(in0 - c0_) - (int)first[u] - (int)r0, rk1 = (int)(in1 - c1_) - (int)first[u] - (int)r0;
+          int rk0 = (int)(in0 - c0_) - (int)r0, rk1 = (int)(in1 - c1_) - (int)r0;
           uint32_t m0 = w0[u], m1 = w1[u];
           // both dwords of a lane in one loop: it runs for the fullest dword of the wave (4-5 starts where a
           // macroblock's chroma blocks lie, 2 in luma), not for the sum of the two
@@ -477,40 +508,69 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
   }
 }
 
-// A walker that had not fallen into step by the end of its lead is walked again, this time from a byte
-// that is known to start a (macro)block if its predecessor is right (the second k_spec_verify pass checks
-// exactly that): one WAVE per such chunk, the block-by-block walker of rtj_decode_kernels.h (a lane-serial
-// walker would take as long for one chunk as k_spec_walk takes for all).  grid: any; loops over the list.
+// A walker that had not fallen into step by the end of its lead is walked again, this time from a byte that is known
+// to start a (macro)block if its predecessor is right (the second k_spec_verify pass checks exactly that): one WAVE per
+// such walker, the block-by-block walker of rtj_decode_kernels.h (a lane-serial walker would take as long for one chunk
+// as k_spec_walk takes for all).  Content whose walks lock late — noise of +-24 and more at the highest quality —
+// needs two things round 2's repair did not do, and without them its packets were refused one and all:
+//   * walkers out of step that FOLLOW one another are one wave's job: the byte the second is to start from was read off
+//     the first one's old records, which are what is being replaced.  The wave of a run's first walker goes on into the
+//     next chunk for as long as that chunk's walker is marked as well, each time from the hand-over point it has just
+//     found itself; the waves of the others leave;
+//   * a walker that is NOT marked may still be wrong: it agreed with its predecessor's old records because the two
+//     walks had found each other before either found the true chain.  So behind a repair the wave looks at the next
+//     walker itself and goes on while that one does not take over from the new hand-over point — unless it is the first
+//     of another wave's run (that wave started from what this one has just replaced: such a packet fails the second
+//     proof pass and goes to the exact kernels; rare).
+// The proof stays k_spec_verify's alone: this kernel only rewrites records.  grid: any; waves loop over the list.
 __global__ __launch_bounds__(64) void k_spec_repair(const FrameDev* __restrict__ frames,
                                                      const SpecChunkDev* __restrict__ chunks,
                                                      const uint8_t* __restrict__ stream,
                                                      const QTab* __restrict__ lut, uint32_t* __restrict__ recbits,
                                                      uint32_t* __restrict__ nrec, uint32_t* __restrict__ wstart,
                                                      uint2* __restrict__ hand, const uint2* __restrict__ fix,
-                                                     const uint32_t* __restrict__ nfix) {
+                                                     uint32_t* __restrict__ nfix,
+                                                     const uint8_t* __restrict__ fixflag, uint32_t total) {
   __shared__ uint32_t s_bits[kSpecTilesMax * 4];  // the re-walked span's start bits (at most kSpecSpan bytes)
-  const uint32_t n = *nfix;
+  const uint32_t n = min(*nfix, total);  // (the count also takes the walkers repaired beyond the list: policy's figure)
+  uint32_t extra = 0;
   for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
     const uint2 e = fix[i];
-    const SpecChunkDev sc = chunks[e.x];
-    const FrameDev f = frames[sc.frame];
-    const uint32_t limit = (sc.c + 1u) * (uint32_t)kSpecChunk;  // where the walker's span ends
-    uint32_t take, tail;
-    for (int k = threadIdx.x; k < kSpecTilesMax * 4; k += 64) s_bits[k] = 0u;
-    __syncthreads();
-    const uint32_t cnt = walk_record(f, stream, lut, e.y, sc.c * (uint32_t)kSpecChunk, limit, s_bits,
-                                     (uint32_t)(kSpecTilesMax * 128), take, tail);
-    __syncthreads();
-    for (int k = threadIdx.x; k < kSpecTilesMax * 4; k += 64) recbits[spec_bits_dword(e.x, (uint32_t)k)] = s_bits[k];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      nrec[e.x] = cnt;
-      wstart[e.x] = e.y;
-      hand[e.x] = make_uint2(take, tail);
+    // (a list entry's walker is never a packet's first, so walker e.x - 1 belongs to the same packet)
+    if (fixflag[e.x - 1u]) continue;  // not the first of its run
+    uint32_t w = e.x, from = e.y;
+    const uint32_t frame = chunks[w].frame;
+    const FrameDev f = frames[frame];
+    bool listed = true;  // walker w is on the list (marked)
+    for (int guard = 0; guard < 4096; guard++) {
+      const SpecChunkDev sc = chunks[w];
+      const uint32_t limit = (sc.c + 1u) * (uint32_t)kSpecChunk;  // where the walker's span ends
+      uint32_t take, tail;
+      for (int k = threadIdx.x; k < kSpecTilesMax * 4; k += 64) s_bits[k] = 0u;
+      __syncthreads();
+      const uint32_t cnt = walk_record(f, stream, lut, from, sc.c * (uint32_t)kSpecChunk, limit, s_bits,
+                                       (uint32_t)(kSpecTilesMax * 128), take, tail);
+      __syncthreads();
+      for (int k = threadIdx.x; k < kSpecTilesMax * 4; k += 64) recbits[spec_bits_dword(w, (uint32_t)k)] = s_bits[k];
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        nrec[w] = cnt;
+        wstart[w] = from;
+        hand[w] = make_uint2(take, tail);
+      }
+      if (!listed) extra++;
+      from += tail & 0xFFFFu;  // the last (macro)block start below the end of this chunk: where the next walker takes over
+      // wave-uniform from here: does the next walker of this packet need the same?
+      if (w + 1u >= total || chunks[w + 1u].frame != frame) break;
+      const bool next_listed = fixflag[w + 1u] != 0;
+      if (next_listed && !listed) break;  // the first of another wave's run
+      if (!next_listed && wstart[w + 1u] + (hand[w + 1u].x & 0xFFFFu) == from) break;  // it takes over where it should
+      listed = next_listed;
+      w++;
     }
   }
+  if (threadIdx.x == 0 && extra) atomicAdd(nfix, extra);
 }
-
 
 // After k_spec_verify, one workgroup.  todo_cnt[0] = packets refused in this launch, todo_cnt[1..] = the list.
 // The plan's walkers start with the short lead.  A launch in which more than 1/32 of them had to be walked
@@ -536,18 +596,23 @@ __global__ __launch_bounds__(256) void k_spec_policy(uint32_t n, uint32_t walker
     // kernels would have been quicker
     const uint32_t nf = *nfix;
     const bool lost = todo_cnt[0] == n || 4u * (uint64_t)nf > walkers;
-    if (!state[kSpecStLong]) {
-      if (lost || 32u * (uint64_t)nf > walkers) {
-        state[kSpecStLong] = 1u;
-        state[kSpecStQuiet] = 0u;
+    const uint32_t level = state[kSpecStLong];  // 0 / 1 / 2: the lead of kSpecLead / kSpecLeadLong / kSpecLeadVery bytes
+    if (level < 2u && (lost || 32u * (uint64_t)nf > walkers)) {
+      state[kSpecStLong] = level + 1u;  // many walkers lock late: the next longer lead
+      state[kSpecStQuiet] = 0u;
+      state[kSpecStLost] = 0u;
+    } else if (level > 0u) {
+      if (level == 2u) {  // nothing longer to try: two lost launches in a row pause the speculation
+        const uint32_t streak = lost ? state[kSpecStLost] + 1u : 0u;
+        state[kSpecStLost] = streak;
+        if (streak >= 2u) state[kSpecStPause] = (uint32_t)kSpecPauseLaunches;
       }
-    } else {
-      const uint32_t streak = lost ? state[kSpecStLost] + 1u : 0u;
-      state[kSpecStLost] = streak;
-      if (streak >= 2u) state[kSpecStPause] = (uint32_t)kSpecPauseLaunches;
       const uint32_t quiet = !lost && 32768u * (uint64_t)nf < walkers ? state[kSpecStQuiet] + 1u : 0u;
       state[kSpecStQuiet] = quiet;
-      if (quiet >= (uint32_t)kSpecQuietLaunches) state[kSpecStLong] = 0u;
+      if (quiet >= (uint32_t)kSpecQuietLaunches) {  // comfortable for a while: try the next shorter lead again
+        state[kSpecStLong] = level - 1u;
+        state[kSpecStQuiet] = 0u;
+      }
     }
   }
 }
