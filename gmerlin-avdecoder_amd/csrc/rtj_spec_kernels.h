@@ -592,10 +592,11 @@ __global__ __launch_bounds__(256) void k_spec_policy(uint32_t n, uint32_t walker
       if (pause == 1u) state[kSpecStLost] = 1u;  // one more lost launch pauses again
     }
   } else if (threadIdx.x == 0) {
-    // a lost launch: every packet refused, or so many walkers repaired (one wave each) that the exact
-    // kernels would have been quicker
+    // a lost launch: more than half of the packets refused (they pay for the walkers AND for the exact kernels:
+    // noise of +-36 at the highest quality ran at 87 K pictures per second that way, against 144 K with the exact
+    // kernels alone), or so many walkers repaired (one wave each) that the exact kernels would have been quicker
     const uint32_t nf = *nfix;
-    const bool lost = todo_cnt[0] == n || 4u * (uint64_t)nf > walkers;
+    const bool lost = 2u * (uint64_t)todo_cnt[0] > n || 4u * (uint64_t)nf > walkers;
     const uint32_t level = state[kSpecStLong];  // 0 / 1 / 2: the lead of kSpecLead / kSpecLeadLong / kSpecLeadVery bytes
     if (level < 2u && (lost || 32u * (uint64_t)nf > walkers)) {
       state[kSpecStLong] = level + 1u;  // many walkers lock late: the next longer lead
