@@ -13,15 +13,13 @@ one = [v for k, v in r.items() if isinstance(v, dict) and 'in flight' in k][0]
 print(f"{sys.argv[1]:66s} {one.get('fps')}", r.get('two_streams_two_threads', {}).get('fps', ''))
 PY
 }
-python tools/pcie_probe.py
-numactl --hardware 2>/dev/null | head -5; nproc
+for rep in 1 2 3; do
 run "pairs, depth 6" X=1
-run "pairs, depth 6, non-coherent host pictures" MI_RTJ_HOST_FLAGS=1
-run "pairs, depth 6, coherent host pictures" MI_RTJ_HOST_FLAGS=2
-run "pairs, depth 6, write-combined host pictures" MI_RTJ_HOST_FLAGS=4
 run "pairs, depth 8" DEPTH=8
-run "pairs, depth 10" DEPTH=10
+run "fours, depth 8" MI_RTJ_OUT_GROUP=4 DEPTH=8
 run "fours, depth 12" MI_RTJ_OUT_GROUP=4 DEPTH=12
 run "fours, depth 16" MI_RTJ_OUT_GROUP=4 DEPTH=16
-run "fours, depth 12, non-coherent" MI_RTJ_OUT_GROUP=4 DEPTH=12 MI_RTJ_HOST_FLAGS=1
-run "4K: pairs, depth 6, non-coherent" W=3840 H=2160 PK=24 REP=8 DEPTH=6 MI_RTJ_HOST_FLAGS=1
+done
+run "4K: pairs, depth 6" W=3840 H=2160 PK=24 REP=8 DEPTH=6
+run "4K: fours, depth 8" W=3840 H=2160 PK=24 REP=8 DEPTH=8 MI_RTJ_OUT_GROUP=4
+run "4K: fours, depth 12" W=3840 H=2160 PK=24 REP=8 DEPTH=12 MI_RTJ_OUT_GROUP=4
