@@ -70,12 +70,16 @@ constexpr int kSpecTile = 128;    // bytes per lane fetched at a time (one cache
 // write per byte, flush checks every 16 bytes, 4 KB reserved per walker and a cap of 2048 blocks per span; the bits
 // cost k_spec_verify a rank-to-position step per chunk (a popcount scan over at most 112 dwords) and need no cap.
 constexpr int kSpecTilesMax = kSpecSpan / kSpecTile;  // tiles of the longest span: a walker's bits are 16 bytes per tile
-__host__ __device__ constexpr size_t spec_bits_words(uint64_t walkers) {  // dwords of the bit buffer (+ a spare walker)
-  return (size_t)((walkers + 1 + 63) / 64) * (size_t)kSpecTilesMax * 64u * 4u;
+__host__ __device__ constexpr size_t spec_bits_words(uint64_t walkers) {  // dwords of the bit buffer (whole waves of walkers)
+  return (size_t)((walkers + 1 + 63) / 64) * 64u * (size_t)kSpecTilesMax * 4u;
 }
-// dword k (positions 32 k .. 32 k + 31) of a walker's bits, in dwords from the start of the buffer
+// dword k (positions 32 k .. 32 k + 31) of a walker's bits, in dwords from the start of the buffer: a walker's bits
+// are CONTIGUOUS (kSpecTilesMax * 16 bytes), so that k_spec_verify reads a chunk's 80 dwords as a few whole lines.  The
+// walkers, which produce 16 bytes per lane and tile, hand four tiles at a time through LDS so that four lanes store 64
+// contiguous bytes of one walker (k_spec_walk).  Round 3's first layout, [tile][lane] per wave of walkers, made the
+// walker's stores contiguous and k_spec_verify's reads 16-byte pieces 1 KB apart (profiles/r03/ab_bits_layout.txt).
 __host__ __device__ constexpr size_t spec_bits_dword(uint32_t walker, uint32_t k) {
-  return (((size_t)(walker >> 6) * (size_t)kSpecTilesMax + (k >> 2)) * 64u + (walker & 63u)) * 4u + (k & 3u);
+  return (size_t)walker * (size_t)(kSpecTilesMax * 4) + k;
 }
 constexpr uint64_t kSpecMinWalkers = 40000;  // below this (~100 MB of packets) the exact kernels index a batch faster:
                                             // a walker is one lane and runs ~0.35 ms whatever the batch (host policy)
@@ -260,7 +264,23 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
   uint32_t take = 0;  // where this walker's chunk takes over from its predecessor (chunk 0: byte 0, record 0)
   uint32_t tail = 0;  // where the next chunk has to take over: the last unit start below the end of this one
   uint32_t cnt_end = 0;  // block starts below the end of the walker's chunk
-  uint32_t* const out_bits = recbits + spec_bits_dword(gw, 0);
+  // Four tiles' bits (the ring) leave together, transposed: store instruction j has lane l write tile (l & 3) of the
+  // wave's walker 16 j + (l >> 2) — four lanes, 64 contiguous bytes of one walker.
+  const uint32_t wave_w0 = blockIdx.x * 64u;  // the wave's first walker (idle lanes of the last wave: spare walkers)
+  auto store_group = [&](int tg) {             // tiles 4 tg .. 4 tg + 3
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the ring's writes before its reads (one wave: in order)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t wl = 16u * (uint32_t)j + ((uint32_t)lane >> 2), pc = (uint32_t)lane & 3u;
+      const uint4 v = *(const uint4*)(s_ring + wl * kSpecRingRow + pc * 16u);
+      *(uint4*)(recbits + spec_bits_dword(wave_w0 + wl, (uint32_t)(4 * tg) * 4u + pc * 4u)) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // ... and its reads before the next tile overwrites a slot
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
   uint4 tb = make_uint4(0, 0, 0, 0);  // the tile's start bits
 
   request(0);
@@ -279,9 +299,9 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
     uint32_t cur[33];
 #pragma unroll
     for (int k = 0; k < 33; k++) cur[k] = buf[k];
-    // the bits of the tile before leave now, BEFORE the next tile's loads are queued: loads and stores
+    // the bits of the four tiles before leave now, BEFORE the next tile's loads are queued: loads and stores
     // complete in order, so a store queued after those loads would have to be waited for with them
-    if (t > 0) *(uint4*)(out_bits + (size_t)(t - 1) * 256u) = tb;
+    if (t > 0 && (t & 3) == 0) store_group(t / 4 - 1);
     if (t + 1 < kSpan / kSpecTile) request(t + 1);  // in flight while this tile is parsed
     // the first byte's token value and weight; every step computes them for the byte after it
     int tm_, wtm_;
@@ -331,7 +351,9 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
     cnt += (uint32_t)(__builtin_popcount(bw[0]) + __builtin_popcount(bw[1]) + __builtin_popcount(bw[2]) +
                       __builtin_popcount(bw[3]));
   }
-  *(uint4*)(out_bits + (size_t)(kSpan / kSpecTile - 1) * 256u) = tb;
+  // the last group, whole or not (slots of tiles the walker never reached hold older tiles' bits: starts "past the span",
+  // which k_spec_verify's rank window never reaches)
+  store_group((kSpan / kSpecTile - 1) / 4);
   if (end_tile == kSpan / kSpecTile) {  // (walkers with the whole lead end with the loop)
     tail = last_aligned_below(kSpan / kSpecTile);
     cnt_end = cnt;
@@ -430,7 +452,7 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
     // 0 .. m - 1 are this chunk's blocks.  A wave works on kSpecVerBatch chunks at a time so that it waits for memory
     // once per batch.
     constexpr uint32_t kWaves = kSpecVerThreads / 64;
-    static_assert((kSpecChunk + kEntries) / 32 + 2 <= 128, "two dwords of start bits per lane");
+    static_assert((kSpecChunk + kEntries) / 32 + 2 + 3 <= 128, "two dwords of start bits per lane");
     // (a wave taking kSpecVerBatch NEIGHBOURING chunks, whose walkers' bits share lines, measured the same:
     // profiles/r03/ab_verify_adjacent_chunks.txt)
     for (uint32_t j0 = (uint32_t)wv; j0 < tile_n; j0 += kSpecVerBatch * kWaves) {
@@ -445,10 +467,20 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
         start[u] = wstart[sc0 + c0 + j];
         first[u] = s_i0[j];
         const uint32_t R = sc0 + c0 + j;  // the walker whose starts are copied
-        const uint32_t k0 = (first[u] >> 5) + (uint32_t)lane, k1 = k0 + 64u;  // dwords from the hand-over point on
-        w0[u] = m[u] && k0 < (uint32_t)(kSpecTilesMax * 4) ? recbits[spec_bits_dword(R, k0)] : 0u;
+#ifdef MIRTJ_EXP_VER_FROM_ZERO  // A/B (short leads only): every bit of the span, ranks counted from the walker's first byte
+        w0[u] = m[u] ? recbits[spec_bits_dword(R, (uint32_t)lane)] : 0u;
+        w1[u] = m[u] ? recbits[spec_bits_dword(R, (uint32_t)lane + 64u)] : 0u;
+        first[u] = c0 + j < nsc && c0 + j ? hand[sc0 + c0 + j].x >> 16 : 0u;
+        continue;
+#endif
+        // dwords from the 16-byte piece that holds the hand-over point on: four lanes then read one piece (the pieces of
+        // a walker lie 1 KB apart); started at the hand-over point's own dword, lane quads straddled two pieces and the
+        // kernel took 2.04 ms per 16,384 pictures instead of 1.60 (profiles/r03/ab_verify_bit_addressing.txt)
+        const uint32_t kt = first[u] >> 5;  // the dword of the hand-over point
+        const uint32_t k0 = (kt & ~3u) + (uint32_t)lane, k1 = k0 + 64u;
+        w0[u] = m[u] && k0 >= kt && k0 < (uint32_t)(kSpecTilesMax * 4) ? recbits[spec_bits_dword(R, k0)] : 0u;
         w1[u] = m[u] && k1 < (uint32_t)(kSpecTilesMax * 4) ? recbits[spec_bits_dword(R, k1)] : 0u;
-        if (lane == 0) w0[u] &= 0xFFFFFFFFu >> (first[u] & 31u);  // starts before the hand-over point (bit 31 = first byte)
+        if (k0 == kt) w0[u] &= 0xFFFFFFFFu >> (first[u] & 31u);  // starts before the hand-over point (bit 31 = first byte)
       }
 #pragma unroll
       for (int u = 0; u < kSpecVerBatch; u++) {
@@ -458,7 +490,11 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
         const uint32_t tot0 = (uint32_t)__builtin_amdgcn_readlane((int)in0, 63);
         const uint32_t in1 = wave_incl_scan(c1_) + tot0;
         uint32_t* const o = out + base[u];
-        const uint32_t q0 = (first[u] & ~31u) + 32u * (uint32_t)lane, q1 = q0 + 2048u;  // walker-relative position of the dwords' first byte
+#ifdef MIRTJ_EXP_VER_FROM_ZERO
+        const uint32_t q0 = 32u * (uint32_t)lane, q1 = q0 + 2048u;
+#else
+        const uint32_t q0 = (first[u] & ~127u) + 32u * (uint32_t)lane, q1 = q0 + 2048u;  // walker-relative position of the dwords' first byte
+#endif
         // Ranks are scattered over the lanes (a lane owns the starts of its 32 bytes), the index wants them in order:
         // written straight to memory, a store instruction touched a dozen 64-byte pieces for 64 offsets and the kernel
         // took 2.1 ms per 16384 pictures.  The offsets are therefore put in rank order in LDS (scattered 16-bit writes
@@ -467,7 +503,11 @@ __global__ __launch_bounds__(kSpecVerThreads) void k_spec_verify(const FrameDev*
         uint16_t* const sp = s_pos[wv];
         for (uint32_t r0 = 0; r0 < m[u]; r0 += (uint32_t)kSpecVerWindow) {
           const uint32_t span_ = min((uint32_t)kSpecVerWindow, m[u] - r0);
+#ifdef MIRTJ_EXP_VER_FROM_ZERO
+          int rk0 = (int)(in0 - c0_) - (int)first[u] - (int)r0, rk1 = (int)(in1 - c1_) - (int)first[u] - (int)r0;
+#else
           int rk0 = (int)(in0 - c0_) - (int)r0, rk1 = (int)(in1 - c1_) - (int)r0;
+#endif
           uint32_t m0 = w0[u], m1 = w1[u];
           // both dwords of a lane in one loop: it runs for the fullest dword of the wave (4-5 starts where a
           // macroblock's chroma blocks lie, 2 in luma), not for the sum of the two
