@@ -70,16 +70,14 @@ constexpr int kSpecTile = 128;    // bytes per lane fetched at a time (one cache
 // write per byte, flush checks every 16 bytes, 4 KB reserved per walker and a cap of 2048 blocks per span; the bits
 // cost k_spec_verify a rank-to-position step per chunk (a popcount scan over at most 112 dwords) and need no cap.
 constexpr int kSpecTilesMax = kSpecSpan / kSpecTile;  // tiles of the longest span: a walker's bits are 16 bytes per tile
-__host__ __device__ constexpr size_t spec_bits_words(uint64_t walkers) {  // dwords of the bit buffer (whole waves of walkers)
-  return (size_t)((walkers + 1 + 63) / 64) * 64u * (size_t)kSpecTilesMax * 4u;
+__host__ __device__ constexpr size_t spec_bits_words(uint64_t walkers) {  // dwords of the bit buffer (+ a spare walker)
+  return (size_t)((walkers + 1 + 63) / 64) * (size_t)kSpecTilesMax * 64u * 4u;
 }
-// dword k (positions 32 k .. 32 k + 31) of a walker's bits, in dwords from the start of the buffer: a walker's bits
-// are CONTIGUOUS (kSpecTilesMax * 16 bytes), so that k_spec_verify reads a chunk's 80 dwords as a few whole lines.  The
-// walkers, which produce 16 bytes per lane and tile, hand four tiles at a time through LDS so that four lanes store 64
-// contiguous bytes of one walker (k_spec_walk).  Round 3's first layout, [tile][lane] per wave of walkers, made the
-// walker's stores contiguous and k_spec_verify's reads 16-byte pieces 1 KB apart (profiles/r03/ab_bits_layout.txt).
+// dword k (positions 32 k .. 32 k + 31) of a walker's bits, in dwords from the start of the buffer: [wave of walkers]
+// [tile][lane][4].  (A layout with each walker's bits contiguous, the walkers transposing four tiles at a time through
+// LDS, was tried at the end of round 3 and did not pass the GPU tests; it is not in the tree.)
 __host__ __device__ constexpr size_t spec_bits_dword(uint32_t walker, uint32_t k) {
-  return (size_t)walker * (size_t)(kSpecTilesMax * 4) + k;
+  return (((size_t)(walker >> 6) * (size_t)kSpecTilesMax + (k >> 2)) * 64u + (walker & 63u)) * 4u + (k & 3u);
 }
 constexpr uint64_t kSpecMinWalkers = 40000;  // below this (~100 MB of packets) the exact kernels index a batch faster:
                                             // a walker is one lane and runs ~0.35 ms whatever the batch (host policy)
@@ -264,23 +262,7 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
   uint32_t take = 0;  // where this walker's chunk takes over from its predecessor (chunk 0: byte 0, record 0)
   uint32_t tail = 0;  // where the next chunk has to take over: the last unit start below the end of this one
   uint32_t cnt_end = 0;  // block starts below the end of the walker's chunk
-  // Four tiles' bits (the ring) leave together, transposed: store instruction j has lane l write tile (l & 3) of the
-  // wave's walker 16 j + (l >> 2) — four lanes, 64 contiguous bytes of one walker.
-  const uint32_t wave_w0 = blockIdx.x * 64u;  // the wave's first walker (idle lanes of the last wave: spare walkers)
-  auto store_group = [&](int tg) {             // tiles 4 tg .. 4 tg + 3
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the ring's writes before its reads (one wave: in order)
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const uint32_t wl = 16u * (uint32_t)j + ((uint32_t)lane >> 2), pc = (uint32_t)lane & 3u;
-      const uint4 v = *(const uint4*)(s_ring + wl * kSpecRingRow + pc * 16u);
-      *(uint4*)(recbits + spec_bits_dword(wave_w0 + wl, (uint32_t)(4 * tg) * 4u + pc * 4u)) = v;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // ... and its reads before the next tile overwrites a slot
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  };
+  uint32_t* const out_bits = recbits + spec_bits_dword(gw, 0);
   uint4 tb = make_uint4(0, 0, 0, 0);  // the tile's start bits
 
   request(0);
@@ -299,9 +281,9 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
     uint32_t cur[33];
 #pragma unroll
     for (int k = 0; k < 33; k++) cur[k] = buf[k];
-    // the bits of the four tiles before leave now, BEFORE the next tile's loads are queued: loads and stores
+    // the bits of the tile before leave now, BEFORE the next tile's loads are queued: loads and stores
     // complete in order, so a store queued after those loads would have to be waited for with them
-    if (t > 0 && (t & 3) == 0) store_group(t / 4 - 1);
+    if (t > 0) *(uint4*)(out_bits + (size_t)(t - 1) * 256u) = tb;
     if (t + 1 < kSpan / kSpecTile) request(t + 1);  // in flight while this tile is parsed
     // the first byte's token value and weight; every step computes them for the byte after it
     int tm_, wtm_;
@@ -351,9 +333,7 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
     cnt += (uint32_t)(__builtin_popcount(bw[0]) + __builtin_popcount(bw[1]) + __builtin_popcount(bw[2]) +
                       __builtin_popcount(bw[3]));
   }
-  // the last group, whole or not (slots of tiles the walker never reached hold older tiles' bits: starts "past the span",
-  // which k_spec_verify's rank window never reaches)
-  store_group((kSpan / kSpecTile - 1) / 4);
+  *(uint4*)(out_bits + (size_t)(kSpan / kSpecTile - 1) * 256u) = tb;
   if (end_tile == kSpan / kSpecTile) {  // (walkers with the whole lead end with the loop)
     tail = last_aligned_below(kSpan / kSpecTile);
     cnt_end = cnt;
