@@ -443,14 +443,16 @@ def main():
         if world == 1 and not a.no_e2e:
             try:
                 e2e = importlib.import_module("tools.e2e_bench")
-                r2 = e2e.run(w, h, packets=min(n, 64), repeat=16)
+                r2 = e2e.run(w, h, packets=min(n, 64), repeat=17)  # the first lap is not timed (the session's allocations)
                 two = r2.pop("two_streams_two_threads", {})
                 out["end_to_end"] = {"fps": max((v.get("fps", 0) for v in r2.values() if isinstance(v, dict)), default=0),
                                      "two_streams_fps": two.get("fps"),
-                                     "pcie_cap_fps": r2["pcie_cap_fps"], "by_flavour": {k: v for k, v in r2.items() if isinstance(v, dict)},
+                                     "pcie_cap_fps": r2["pcie_cap_fps"], "workload": r2.get("workload"), "by_flavour": {k: v for k, v in r2.items() if isinstance(v, dict)},
                                      "note": "fps: ONE stream, one host thread, through csrc/video_rtjpeg_mi355x.c, the best "
                                              "flavour (its default build: frame-owning with packets in flight, pictures leaving on "
                                              "two copy streams); two_streams_fps: two instances on two threads, aggregate; "
+                                             "the clock starts behind the first lap of the packet list (a session allocates its "
+                                             "buffers while its first packets come in: the W untimed steps of this contract); "
                                              "pcie_cap_fps = what the host link gives ONE picture-sized pinned copy at a time "
                                              "(38.4 GB/s for 3.1 MB, tools/pcie_probe.py) / picture bytes — the cap of round 2's "
                                              "sessions, which had one copy out in flight"}
@@ -466,14 +468,18 @@ def main():
     dev.free(r["d_out"])
     barrier()  # ranks other than 0 wait here while rank 0 times the CPU legs
 
-    # the same step at other launch sizes: 3 timed steps each, fresh frames, never part of `value`
+    # the same step at other launch sizes, fresh frames, never part of `value`
     if world == 1 and rank == 0 and not a.no_sweep:
         sweep = {}
         for nb in (256, 1024, 4096):
             if nb >= n:
                 continue
-            sw = run_frames(a, dev, rank, nb, a.amp, 3, 2, barrier, sync_all)
-            sweep[str(nb)] = {"frames_per_s": round(nb * 3 / sw["dt"], 1),
+            # enough steps for the steady state to show: plans of these sizes build the index of step k + 1 while step k
+            # is transformed, and the first steps of a run have nothing to overlap with (round 3 first timed 3 steps
+            # after 2 and reported a 1024-picture launch 13 % below what a run of 30 gives)
+            sw_steps = max(8, min(64, 32768 // nb))
+            sw = run_frames(a, dev, rank, nb, a.amp, sw_steps, 6, barrier, sync_all)
+            sweep[str(nb)] = {"frames_per_s": round(nb * sw_steps / sw["dt"], 1), "steps": sw_steps,
                               "steps_overlap": 129 <= nb < 8192 and w * h == 1920 * 1088,  # mi_rtjpeg.hip: plan overlap policy
                               "kernels_ms": {k: round(v / max(sw["launches"], 1), 4) for k, v in sw["ktimes"].items() if v > 0},
                               "index": "speculative" if sw["plan"].spec_stats()[1] else "exact"}
@@ -482,8 +488,8 @@ def main():
             dev.free(sw["d_out"])
         sweep[str(n)] = {"frames_per_s": out["value"], "kernels_ms": {k: v["ms"] for k, v in out["kernels"].items()},
                          "index": "speculative" if out["speculative_index"]["stream_chunks"] else "exact"}
-        out["by_batch"] = dict(sweep, note="frames per launch -> whole-step frames/s (3 timed steps, 2 warm-up; the last "
-                                           "entry is the headline run).  steps_overlap: plans of that size build the index of "
+        out["by_batch"] = dict(sweep, note="frames per launch -> whole-step frames/s (`steps` timed steps after 6 warm-up steps; "
+                                           "the last entry is the headline run).  steps_overlap: plans of that size build the index of "
                                            "step k + 1 while step k is transformed; their kernels share the device, so kernels_ms "
                                            "of those entries are not kernel costs (the headline's are: its kernels run back to back)")
 

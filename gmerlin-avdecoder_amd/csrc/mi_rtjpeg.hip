@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -167,6 +168,10 @@ struct mi_rtj_pipe {
                        // picture, instead of the copy engine (A/B)
   int exp_skip = 0;    // MI_RTJ_EXP_SKIP (experiments, wrong pictures): 1 no copy out, 2 no kernels, 4 no copy in
   uint64_t submitted = 0, returned = 0;
+  // MI_RTJ_PIPE_STATS=1: where the submitting thread's time goes (seconds; printed to stderr when the session ends):
+  // [0] copying packets into pinned staging, [1] runtime calls that queue work, [2] waiting for a picture's copy out
+  bool stats = false;
+  double t_stage = 0, t_issue = 0, t_wait = 0, t_d2h_call = 0;  // t_d2h_call: inside hipMemcpyAsync of the copy out (part of t_issue)
   // The thread that submits is what bounds a session (about 50 us of runtime calls per packet next to the 30 us it
   // takes to copy a 1080p packet into pinned staging), so the two halves run on two threads: the caller copies, a
   // worker owned by the session makes the HIP calls, in submission order.
@@ -329,6 +334,7 @@ int plan_alloc_chunks(mi_rtj_plan* p) {
       HIPCHK(c, hipMalloc((void**)&p->d_spec_hand, sizeof(uint2) * p->n_spec));
       HIPCHK(c, hipMalloc((void**)&p->d_spec_fix, sizeof(uint2) * p->n_spec));
       HIPCHK(c, hipMalloc((void**)&p->d_spec_flag, p->n_spec + 64));
+      HIPCHK(c, hipMemsetAsync(p->d_spec_flag, 0, p->n_spec + 64, c->stream));  // (the walkers zero [0, n_spec) per launch)
       if (!p->d_spec_nfix) {
         HIPCHK(c, hipMalloc((void**)&p->d_spec_nfix, sizeof(uint32_t)));
         HIPCHK(c, hipMemsetAsync(p->d_spec_nfix, 0, sizeof(uint32_t), c->stream));
@@ -424,28 +430,26 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
       ntodo = p->d_spec_todo;
       todo = p->d_spec_todo + 1;
       rows = std::min<unsigned>(rows, kSpecFallbackRows);
-      HIPCHK(c, hipMemsetAsync(p->d_spec_todo, 0, sizeof(uint32_t), is));
-      HIPCHK(c, hipMemsetAsync(p->d_spec_nfix, 0, sizeof(uint32_t), is));
-      HIPCHK(c, hipMemsetAsync(p->d_spec_flag, 0, p->n_spec + 64, is));
       if ((rc = begin(MI_RTJ_K_SPEC_WALK)) != MI_RTJ_OK) return rc;
-      // both walker forms (short and long lead) are queued; the one the policy state does not name returns at once
+      // The walkers zero the launch's lists themselves (SpecReset).  With a policy ONE dispatch runs the form the
+      // policy's state names (or returns at once while the speculation is paused); without (MI_RTJ_SPEC = 1 / 3 / 4:
+      // tests) the form asked for.
       const dim3 wgrid((unsigned)((p->n_spec + 63) / 64));
-#define MIRTJ_LAUNCH_WALK(PHASE, LEAD)                                                                                  \
-  hipLaunchKernelGGL((k_spec_walk<PHASE, LEAD>), wgrid, dim3(64), 0, is, p->d_frames, p->d_spec_chunks,         \
-                     (uint32_t)p->n_spec, st, c->d_lut, p->d_spec_rec, p->d_spec_nrec, p->d_spec_wstart, p->d_spec_hand, \
-                     state)
-      // with the policy (state) all three forms are queued and the two it does not name return at once; without it
-      // (MI_RTJ_SPEC = 1 / 3 / 4: tests) only the form asked for
-      if (p->one_block_type) {
-        if (state || p->spec_mode == 1) MIRTJ_LAUNCH_WALK(false, kSpecLead);
-        if (state || p->spec_mode == 3) MIRTJ_LAUNCH_WALK(false, kSpecLeadLong);
-        if (state || p->spec_mode == 4) MIRTJ_LAUNCH_WALK(false, kSpecLeadVery);
+      const SpecReset rs{p->d_spec_nfix, p->d_spec_todo, p->d_spec_flag};
+#define MIRTJ_WALK_ARGS p->d_frames, p->d_spec_chunks, (uint32_t)p->n_spec, st, c->d_lut, p->d_spec_rec, p->d_spec_nrec, p->d_spec_wstart, p->d_spec_hand, rs
+      if (state) {
+        if (p->one_block_type) hipLaunchKernelGGL((k_spec_walk_any<false>), wgrid, dim3(64), 0, is, MIRTJ_WALK_ARGS, state);
+        else hipLaunchKernelGGL((k_spec_walk_any<true>), wgrid, dim3(64), 0, is, MIRTJ_WALK_ARGS, state);
+      } else if (p->one_block_type) {
+        if (p->spec_mode == 1) hipLaunchKernelGGL((k_spec_walk<false, kSpecLead>), wgrid, dim3(64), 0, is, MIRTJ_WALK_ARGS);
+        if (p->spec_mode == 3) hipLaunchKernelGGL((k_spec_walk<false, kSpecLeadLong>), wgrid, dim3(64), 0, is, MIRTJ_WALK_ARGS);
+        if (p->spec_mode == 4) hipLaunchKernelGGL((k_spec_walk<false, kSpecLeadVery>), wgrid, dim3(64), 0, is, MIRTJ_WALK_ARGS);
       } else {
-        if (state || p->spec_mode == 1) MIRTJ_LAUNCH_WALK(true, kSpecLead);
-        if (state || p->spec_mode == 3) MIRTJ_LAUNCH_WALK(true, kSpecLeadLong);
-        if (state || p->spec_mode == 4) MIRTJ_LAUNCH_WALK(true, kSpecLeadVery);
+        if (p->spec_mode == 1) hipLaunchKernelGGL((k_spec_walk<true, kSpecLead>), wgrid, dim3(64), 0, is, MIRTJ_WALK_ARGS);
+        if (p->spec_mode == 3) hipLaunchKernelGGL((k_spec_walk<true, kSpecLeadLong>), wgrid, dim3(64), 0, is, MIRTJ_WALK_ARGS);
+        if (p->spec_mode == 4) hipLaunchKernelGGL((k_spec_walk<true, kSpecLeadVery>), wgrid, dim3(64), 0, is, MIRTJ_WALK_ARGS);
       }
-#undef MIRTJ_LAUNCH_WALK
+#undef MIRTJ_WALK_ARGS
       if ((rc = end(MI_RTJ_K_SPEC_WALK)) != MI_RTJ_OK) return rc;
       if ((rc = begin(MI_RTJ_K_SPEC_VERIFY)) != MI_RTJ_OK) return rc;
       // first pass; walkers that had not fallen into step are walked again from a known block start; second
@@ -455,7 +459,7 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
                          p->d_spec_wstart, p->d_spec_hand, p->d_spec_fix, p->d_spec_nfix, p->d_spec_flag, 1);
       hipLaunchKernelGGL(k_spec_repair, dim3(kSpecRepairGrid), dim3(64), 0, is, p->d_frames, p->d_spec_chunks, st,
                          c->d_lut, p->d_spec_rec, p->d_spec_nrec, p->d_spec_wstart, p->d_spec_hand, p->d_spec_fix, p->d_spec_nfix,
-                         p->d_spec_flag, (uint32_t)p->n_spec);
+                         p->d_spec_flag, (uint32_t)p->n_spec, state);
       hipLaunchKernelGGL(k_spec_verify, dim3(p->n), dim3(kSpecVerThreads), 0, is, p->d_frames, p->d_spec_base, c->d_lut,
                          p->d_spec_rec, p->d_spec_nrec, blk, p->d_spec_ok, p->d_spec_todo + 1, p->d_spec_todo, state,
                          p->d_spec_wstart, p->d_spec_hand, p->d_spec_fix, p->d_spec_nfix, p->d_spec_flag, 2);
@@ -1048,6 +1052,9 @@ int mi_rtj_decode_nocopy(mi_rtj_ctx* c, const uint8_t* pkt, size_t len, const ui
 // lib/video_v4l2_m2m.c:43-131 as the in-tree precedent of a decoder with packets in flight).
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
+inline double host_now() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 // everything of one packet that goes to the device: copy in, kernels, copy out (called on the worker thread, or on
 // the caller's when the session runs without one)
 // how the pinned host pictures are allocated (MI_RTJ_HOST_FLAGS, experiments: 1 non-coherent, 2 coherent, 4 write-combined)
@@ -1078,7 +1085,9 @@ int pipe_copy_out(mi_rtj_pipe* q, int last) {
   } else if (q->out_kernel) {
     hipLaunchKernelGGL(k_copy16, dim3(q->out_kernel), dim3(256), 0, so, (const uint4*)a.d_pic, (uint4*)a.h_pic, bytes / 16);
   } else {
+    const double t0 = q->stats ? host_now() : 0.0;
     HIPCHK(c, hipMemcpyAsync(a.h_pic, a.d_pic, bytes, hipMemcpyDeviceToHost, so));
+    if (q->stats) q->t_d2h_call += host_now() - t0;
   }
   HIPCHK(c, hipEventRecord(z.e_out, so));
   for (int i = first; i <= last; i++) {
@@ -1166,6 +1175,8 @@ mi_rtj_pipe* mi_rtj_pipe_create(mi_rtj_ctx* c, int depth, int max_w, int max_h) 
     q->out_kernel = ok_ ? atoi(ok_) : 0;  // the value is the copy kernel's grid (workgroups of 256)
     const char* sk = getenv("MI_RTJ_EXP_SKIP");
     q->exp_skip = sk ? atoi(sk) : 0;
+    const char* ps = getenv("MI_RTJ_PIPE_STATS");
+    q->stats = ps && atoi(ps) != 0;
   }
   {
     const char* og = getenv("MI_RTJ_OUT_GROUP");
@@ -1240,6 +1251,9 @@ mi_rtj_pipe* mi_rtj_pipe_create(mi_rtj_ctx* c, int depth, int max_w, int max_h) 
 void mi_rtj_pipe_destroy(mi_rtj_pipe* q) {
   if (!q) return;
   mi_rtj_ctx* c = q->ctx;
+  if (q->stats && q->returned)
+    fprintf(stderr, "{\"pipe_stats\": {\"pictures\": %llu, \"us_per_picture\": {\"staging_memcpy\": %.1f, \"queueing_calls\": %.1f, \"of_which_the_d2h_memcpy_call\": %.1f, \"waiting_for_copy_out\": %.1f}}}\n",
+            (unsigned long long)q->returned, 1e6 * q->t_stage / q->returned, 1e6 * q->t_issue / q->returned, 1e6 * q->t_d2h_call / q->returned, 1e6 * q->t_wait / q->returned);
   (void)hipSetDevice(c->device);
   if (q->worker.joinable()) {
     {
@@ -1367,8 +1381,10 @@ int mi_rtj_pipe_submit(mi_rtj_pipe* q, const uint8_t* pkt, size_t len, uint64_t 
   // descriptor and packet travel together: one copy in, on its own stream
   FrameDev& fd = p->h_frames[0];  // plan_alloc_chunks has set its chunk bases
   fd.data_off = sizeof(FrameDev) + MI_RTJ_HEADER_SIZE;
+  const double ts0 = q->stats ? host_now() : 0.0;
   memcpy(sl.h_stage, &fd, sizeof(FrameDev));
   memcpy(sl.h_stage + sizeof(FrameDev), pkt, len);
+  if (q->stats) q->t_stage += host_now() - ts0;
   p->d_frames = (FrameDev*)sl.d_stage;
   sl.len = len;
   sl.tag = tag;
@@ -1382,7 +1398,9 @@ int mi_rtj_pipe_submit(mi_rtj_pipe* q, const uint8_t* pkt, size_t len, uint64_t 
   q->count++;
   q->submitted++;
   if (!q->threaded) {
+    const double ti0 = q->stats ? host_now() : 0.0;
     sl.rc = pipe_issue(q, sl);
+    if (q->stats) q->t_issue += host_now() - ti0;
     sl.issued = 1;
     if (sl.rc != MI_RTJ_OK) {  // undo: the packet never went in, its predecessor is still the last picture
       q->count--;
@@ -1428,7 +1446,11 @@ int mi_rtj_pipe_next(mi_rtj_pipe* q, const uint8_t* planes[3], int strides[3], i
     const int rc = pipe_copy_out(q, last);
     if (rc != MI_RTJ_OK) return rc;
   }
-  HIPCHK(c, hipEventSynchronize(sl.out_ev ? sl.out_ev : sl.e_out));
+  {
+    const double tw0 = q->stats ? host_now() : 0.0;
+    HIPCHK(c, hipEventSynchronize(sl.out_ev ? sl.out_ev : sl.e_out));
+    if (q->stats) q->t_wait += host_now() - tw0;
+  }
   sl.out_state = 0;
   if (planes) {
     const size_t ysz = (size_t)sl.w * sl.h;

@@ -167,21 +167,32 @@ constexpr int kSpecVerThreads = MIRTJ_SPEC_VER_THREADS;  // k_spec_verify: chunk
       : [tm] "v"(tm_), [wtm] "v"(wtm_), [wn] "v"(wn_), [k63] "v"(k63), [kn64] "v"(kn64), [rb] "v"(rb)              \
       : "vcc")
 
+// What a launch's walkers zero before anything else of the launch looks at it: the lists k_spec_verify fills (walkers
+// to repair, packets refused) and the per-walker "on the repair list" marks.  (Three memsets in front of the walkers
+// before: three more dispatches per launch, which a launch of 1024 pictures feels.)
+struct SpecReset {
+  uint32_t* nfix;
+  uint32_t* ntodo;
+  uint8_t* fixflag;
+};
+
 template <bool PHASE, int LEAD>
-__global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ frames,
-                                                   const SpecChunkDev* __restrict__ chunks, uint32_t total,
-                                                   const uint8_t* __restrict__ stream,
-                                                   const QTab* __restrict__ lut, uint32_t* __restrict__ recbits,
-                                                   uint32_t* __restrict__ nrec, uint32_t* __restrict__ wstart,
-                                                   uint2* __restrict__ hand, const uint32_t* __restrict__ state) {
-  // both forms are launched; the plan's policy state says which one works (none while paused, k_spec_policy)
-  if (state && (state[kSpecStPause] || spec_lead_of_level(state[kSpecStLong]) != LEAD)) return;
+__device__ __forceinline__ void spec_walk_body(uint8_t* __restrict__ s_ring, const FrameDev* __restrict__ frames,
+                                               const SpecChunkDev* __restrict__ chunks, uint32_t total,
+                                               const uint8_t* __restrict__ stream, const QTab* __restrict__ lut,
+                                               uint32_t* __restrict__ recbits, uint32_t* __restrict__ nrec,
+                                               uint32_t* __restrict__ wstart, uint2* __restrict__ hand,
+                                               const SpecReset rs) {
   constexpr int kSpan = LEAD + kSpecChunk;
   static_assert(kSpan % kSpecTile == 0 && kSpan < 65536, "walker span: whole tiles, 16-bit positions");
-  __shared__ __attribute__((aligned(16))) uint8_t s_ring[64 * kSpecRingRow];
   const int lane = threadIdx.x;
   const uint32_t g = blockIdx.x * 64u + (uint32_t)lane;
   const bool act = g < total;
+  if (act) rs.fixflag[g] = 0;
+  if (g == 0u) {
+    *rs.nfix = 0u;
+    *rs.ntodo = 0u;
+  }
   const SpecChunkDev sc = chunks[act ? g : total - 1u];  // idle lanes shadow the last chunk and store nothing
   const FrameDev f = frames[sc.frame];
   const int lb = lut[f.qidx].lb8 + 1, cb = lut[f.qidx].cb8 + 1;  // DC + raw bytes of a luma / chroma block
@@ -343,6 +354,39 @@ __global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ f
     wstart[g] = start;
     hand[g] = make_uint2(take, tail);  // .y: what the next chunk must take over from
   }
+}
+
+// One form, named by the host (plans without a policy: MI_RTJ_SPEC = 1 / 3 / 4, tests).
+template <bool PHASE, int LEAD>
+__global__ __launch_bounds__(64) void k_spec_walk(const FrameDev* __restrict__ frames,
+                                                   const SpecChunkDev* __restrict__ chunks, uint32_t total,
+                                                   const uint8_t* __restrict__ stream,
+                                                   const QTab* __restrict__ lut, uint32_t* __restrict__ recbits,
+                                                   uint32_t* __restrict__ nrec, uint32_t* __restrict__ wstart,
+                                                   uint2* __restrict__ hand, const SpecReset rs) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_ring[64 * kSpecRingRow];
+  spec_walk_body<PHASE, LEAD>(s_ring, frames, chunks, total, stream, lut, recbits, nrec, wstart, hand, rs);
+}
+
+// The form the plan's policy state names (none while the speculation is paused, k_spec_policy): ONE dispatch whatever
+// the lead.  (Round 3 first queued the three forms as three kernels of which two returned at once.)
+template <bool PHASE>
+__global__ __launch_bounds__(64) void k_spec_walk_any(const FrameDev* __restrict__ frames,
+                                                       const SpecChunkDev* __restrict__ chunks, uint32_t total,
+                                                       const uint8_t* __restrict__ stream,
+                                                       const QTab* __restrict__ lut, uint32_t* __restrict__ recbits,
+                                                       uint32_t* __restrict__ nrec, uint32_t* __restrict__ wstart,
+                                                       uint2* __restrict__ hand, const SpecReset rs,
+                                                       const uint32_t* __restrict__ state) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_ring[64 * kSpecRingRow];
+  if (state[kSpecStPause]) return;
+  const uint32_t level = state[kSpecStLong];  // wave-uniform
+  if (level == 0u)
+    spec_walk_body<PHASE, kSpecLead>(s_ring, frames, chunks, total, stream, lut, recbits, nrec, wstart, hand, rs);
+  else if (level == 1u)
+    spec_walk_body<PHASE, kSpecLeadLong>(s_ring, frames, chunks, total, stream, lut, recbits, nrec, wstart, hand, rs);
+  else
+    spec_walk_body<PHASE, kSpecLeadVery>(s_ring, frames, chunks, total, stream, lut, recbits, nrec, wstart, hand, rs);
 }
 
 // One workgroup per packet: the chain check, the block numbering, and — the numbering is all it needs —
@@ -550,8 +594,10 @@ __global__ __launch_bounds__(64) void k_spec_repair(const FrameDev* __restrict__
                                                      uint32_t* __restrict__ nrec, uint32_t* __restrict__ wstart,
                                                      uint2* __restrict__ hand, const uint2* __restrict__ fix,
                                                      uint32_t* __restrict__ nfix,
-                                                     const uint8_t* __restrict__ fixflag, uint32_t total) {
-  __shared__ uint32_t s_bits[kSpecTilesMax * 4];  // the re-walked span's start bits (at most kSpecSpan bytes)
+                                                     const uint8_t* __restrict__ fixflag, uint32_t total,
+                                                     const uint32_t* __restrict__ state) {
+  __shared__ uint32_t s_bits[kSpecTilesMax * 4];
+  if (state && state[kSpecStPause]) return;  // paused: no walker ran, the list is the last unpaused launch's  // the re-walked span's start bits (at most kSpecSpan bytes)
   const uint32_t n = min(*nfix, total);  // (the count also takes the walkers repaired beyond the list: policy's figure)
   uint32_t extra = 0;
   for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {

@@ -14,6 +14,8 @@
  *                 skipped at the source, s->out_time is set to the first one kept (lib/video.c:596-612)
  *   repeat=R      play the packet list R times (time stamps keep counting); bench=1: write no pictures, print
  *                 {"frames":..,"seconds":..,"fps":..} on stdout (the end-to-end figure of bench.py)
+ *   warm=N        (bench) the clock starts after the first N pictures: a session allocates its buffers while its
+ *                 first packets come in (like the W untimed warm-up steps of bench.py)
  *   streams=K     (bench) K streams side by side, each with its own decoder instance on its own thread, as an
  *                 application playing K files would (doc/mainpage.incl:54-55: instances may run on different threads);
  *                 the figure printed is the aggregate
@@ -125,7 +127,7 @@ static int load_mov(const char *path, queue_t *q, uint32_t *fourcc, int *w, int 
 /* what one stream is asked to do, and what came of it */
 typedef struct {
   const gavl_packet_t *pkts;
-  int n, repeat, iw, ih, skip_every, seek_at, seek_to, skipto_at, skippkts_at, bench;
+  int n, repeat, iw, ih, skip_every, seek_at, seek_to, skipto_at, skippkts_at, bench, warm;
   long long skipto_t, skippkts_t;
   uint32_t fourcc;
   const gavl_dictionary_t *opt;
@@ -231,7 +233,7 @@ static void *play(void *arg) {
       for (int pl = 1; pl < 3; pl++)
         for (int y = 0; y < ch; y++) fwrite(res->planes[pl] + (size_t)y * res->strides[pl], 1, cw, fo);
       fwrite(&res->timestamp, 8, 1, fo);
-    } else { /* bench: touch the picture like a consumer would (one byte per 4 KiB page of every plane) */
+    } else if (!getenv("MI_RTJ_HARNESS_NO_TOUCH")) { /* bench: touch the picture like a consumer would (one byte per 4 KiB page of every plane) */
       volatile unsigned acc = 0;
       for (size_t o = 0; o < (size_t)res->strides[0] * ih; o += 4096) acc += res->planes[0][o];
       for (int pl = 1; pl < 3; pl++)
@@ -239,6 +241,10 @@ static void *play(void *arg) {
       (void)acc;
     }
     nframes++;
+    if (c->bench && nframes == c->warm) { /* warm=N: the first N pictures (the session's allocations) are not timed */
+      clock_gettime(CLOCK_MONOTONIC, &ts);
+      c->t_start = (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+    }
   }
   clock_gettime(CLOCK_MONOTONIC, &ts);
   c->t_end = (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
@@ -247,7 +253,7 @@ static void *play(void *arg) {
   free(f.planes[0]);
   free(f.planes[1]);
   free(f.planes[2]);
-  c->nframes = nframes;
+  c->nframes = c->bench && nframes > c->warm ? nframes - c->warm : nframes;
   return NULL;
 }
 
@@ -269,6 +275,7 @@ int main(int argc, char **argv) {
     if (sscanf(argv[i], "skippkts=%d:%lld", &cfg.skippkts_at, &cfg.skippkts_t) == 2) continue;
     if (sscanf(argv[i], "repeat=%d", &cfg.repeat) == 1) continue;
     if (sscanf(argv[i], "bench=%d", &cfg.bench) == 1) continue;
+    if (sscanf(argv[i], "warm=%d", &cfg.warm) == 1) continue;
     if (sscanf(argv[i], "streams=%d", &streams) == 1) continue;
     if (sscanf(argv[i], "opt=%31[^:]:%d", key, &val) == 2 && opt.n_ints < MI_COMPAT_DICT_INTS) {
       snprintf(opt.ints[opt.n_ints].key, sizeof opt.ints[0].key, "%s", key);

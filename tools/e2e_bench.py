@@ -10,7 +10,8 @@ sys.path.insert(0, ROOT)
 
 
 def run(width=1920, height=1088, packets=64, repeat=32, depth=6, quality=255, amp=8, flavours=("", "_nocopy", "_pipe"),
-        two_streams=True):
+        two_streams=True, warm=None):
+    warm = packets if warm is None else warm  # one lap untimed: the decoder allocates its buffers while the first packets come in
     P = importlib.import_module("gmerlin-avdecoder_amd")
     dev = P.MiRtj(0)
     d_fr = dev.synth(width, height, 0, packets, seed=12345, amp=amp)
@@ -25,7 +26,7 @@ def run(width=1920, height=1088, packets=64, repeat=32, depth=6, quality=255, am
             fh.write(pkt.tobytes())
     dev.free(d_fr); dev.free(d_st); dev.close()
     subprocess.run(["make", "-C", os.path.join(ROOT, "gmerlin-avdecoder_amd", "csrc")], check=True, capture_output=True)
-    out = {"workload": f"{packets} RTjpeg {width}x{height} Q={quality} packets x {repeat} laps, display {width}x{height - 8 if height == 1088 else height}",
+    out = {"workload": f"{packets} RTjpeg {width}x{height} Q={quality} packets x {repeat} laps (the first {warm} pictures untimed), display {width}x{height - 8 if height == 1088 else height}",
            # what the host link gives ONE picture-sized pinned copy at a time (tools/pcie_probe.py, profiles/r02/pcie_probe.json:
            # 38.4 GB/s for 3.1 MB, 54.6 GB/s for 12.4 MB): the copy out is what bounds a session
            "pcie_cap_fps": round((38.4e9 if width * height * 1.5 < 6e6 else 54.6e9) / (width * height * 1.5), 0)}
@@ -33,15 +34,18 @@ def run(width=1920, height=1088, packets=64, repeat=32, depth=6, quality=255, am
         exe = os.path.join(ROOT, "gmerlin-avdecoder_amd", "lib", "plugin_harness" + fl)
         env = dict(os.environ, MI_RTJ_DEPTH=str(depth))
         ih = height - 8 if height == 1088 else height
-        r = subprocess.run([exe, path, str(width), str(ih), "/dev/null", f"repeat={repeat}", "bench=1"], capture_output=True, text=True, env=env, timeout=600)
+        r = subprocess.run([exe, path, str(width), str(ih), "/dev/null", f"repeat={repeat}", "bench=1", f"warm={warm}"], capture_output=True, text=True, env=env, timeout=600)
         name = {"": "copy (synchronous, caller's planes; -DMI_RTJ_COPY_MODE)", "_nocopy": "frame-owning (synchronous; -DMI_RTJ_SYNC_NOCOPY)",
                 "_pipe": f"frame-owning, {depth} packets in flight (the default build)"}[fl]
         try:
             out[name] = json.loads(r.stdout.strip().splitlines()[-1])
+            for ln in r.stderr.splitlines():  # MI_RTJ_PIPE_STATS=1: where the submitting thread's time went
+                if ln.startswith('{"pipe_stats"'):
+                    out[name]["pipe_stats"] = json.loads(ln)["pipe_stats"]
         except Exception:
             out[name] = {"error": (r.stderr or r.stdout)[-300:]}
         if fl == "_pipe" and two_streams:  # two decoder instances on two threads of one process: the aggregate
-            r = subprocess.run([exe, path, str(width), str(ih), "/dev/null", f"repeat={repeat}", "bench=1", "streams=2"],
+            r = subprocess.run([exe, path, str(width), str(ih), "/dev/null", f"repeat={repeat}", "bench=1", "streams=2", f"warm={warm}"],
                                capture_output=True, text=True, env=env, timeout=600)
             try:
                 out["two_streams_two_threads"] = json.loads(r.stdout.strip().splitlines()[-1])
