@@ -111,9 +111,10 @@ def run_streams4k(a, dev, shard, dist, red_dev, rank, world, barrier, sync_all, 
     dev.free(d_fr)
     pkts = [dev.d2h(d_st, int(pl[i]), offset=int(po[i])) for i in range(nf)]
     dev.free(d_st)
-    # six packets in flight, the wrapper's default: with four (two pairs) the copy engine idles while the caller
-    # refills a pair (2,820 against 4,130 pictures per second on one box, profiles/r03/e2e_steady_state.txt)
-    pipe = dev.pipe(depth=int(os.environ.get("MI_RTJ_DEPTH_OVERRIDE", "6")), coded_w=w, coded_h=h)
+    # twelve packets in flight, the wrapper's default (pictures leave four at a time): with four in flight (two pairs)
+    # the copy engine idles while the caller refills a pair (2,820 against 4,130 pictures per second on one box,
+    # profiles/r03/e2e_steady_state.txt)
+    pipe = dev.pipe(depth=int(os.environ.get("MI_RTJ_DEPTH_OVERRIDE", "12")), coded_w=w, coded_h=h)
 
     def lap(check=None):
         got, nxt = 0, 0
@@ -136,8 +137,11 @@ def run_streams4k(a, dev, shard, dist, red_dev, rank, world, barrier, sync_all, 
     barrier()
     sync_all()
     t0 = time.perf_counter()
+    lap_ms = []
     for _ in range(a.steps):
+        t1 = time.perf_counter()
         lap()
+        lap_ms.append(round((time.perf_counter() - t1) * 1e3, 3))
     sync_all()
     barrier()
     dt = time.perf_counter() - t0
@@ -162,7 +166,8 @@ def run_streams4k(a, dev, shard, dist, red_dev, rank, world, barrier, sync_all, 
                        "sharding": "streams, one per GPU, no data-path collective"},
            "mpixels_per_s": round(fps * w * h / 1e6, 1),
            "pcie_cap_frames_per_s_per_gpu": round(54.6e9 / (w * h * 1.5), 0),  # 12.4 MB pinned copies: tools/pcie_probe.py
-           "parity_checked": rep.checked, "parity_mismatches": rep.mismatches}
+           "parity_checked": rep.checked, "parity_mismatches": rep.mismatches,
+           "lap_ms": lap_ms}  # rank 0's laps of nf pictures, in order (host-side clock)
     if rank == 0:
         bytes_in = sum(int(p.size) - 12 for p in pkts) / nf
         alg = {"k_decode": bytes_in + w * h * 1.5, "k_index_summarize": bytes_in, "k_index_emit": bytes_in}

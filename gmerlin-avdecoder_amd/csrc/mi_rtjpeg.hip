@@ -133,6 +133,8 @@ struct PipeSlot {
   hipEvent_t e_in = nullptr, e_dec = nullptr, e_out = nullptr;
   uint64_t tag = 0;
   int w = 0, h = 0;
+  FrameDev fd;                      // (index groups) the packet's descriptor, bases filled in when its group is queued
+  int staged = 0;                   // (index groups) 1: copied in, kernels not queued yet
   // hand-over to the session's worker thread (the HIP calls of a packet are made there)
   size_t len = 0;                   // packet bytes in h_stage
   const uint8_t* prev = nullptr;    // predecessor's device picture (or none)
@@ -163,6 +165,18 @@ struct mi_rtj_pipe {
   int group = 1;
   size_t grp_fsz = 0;                  // bytes of one picture in a group buffer
   std::vector<uint8_t*> d_grp, h_grp;  // [depth / group]
+  // The INDEX of the packets is built in groups as well (MI_RTJ_IDX_GROUP = 1 / 2 / 4, default: the copy group): the
+  // exact index of ONE 1080p packet is three launches that each run one round of workgroups or one serial chain
+  // (k_index_summarize 19 us, k_index_resolve 21, k_index_emit 13, tools/one_packet_kernels.py) and take as long for
+  // two or four packets side by side.  A packet is copied in at once and waits ("staged") until its group is complete
+  // or the caller asks for its picture; then one index launch covers the group and k_decode follows packet by packet
+  // (a packet's unchanged blocks come from its predecessor's picture).  One plan per group of slots; the descriptors
+  // of all slots live in one array (pinned + device) so that a group's are contiguous.
+  int igroup = 1;
+  int nstaged = 0;                     // slots staged and not yet queued: the last `nstaged` submitted
+  std::vector<mi_rtj_plan*> gplan;     // [depth / igroup]
+  FrameDev* h_desc = nullptr;          // [depth], pinned
+  FrameDev* d_desc = nullptr;          // [depth]
   hipStream_t s_idx = nullptr;         // MI_RTJ_IDX_STREAM=1 (A/B, slower): index kernels of the packets on a stream of their own
   int out_kernel = 0;  // MI_RTJ_OUT_KERNEL=1: the picture leaves through a copy kernel that stores into the pinned host
                        // picture, instead of the copy engine (A/B)
@@ -375,7 +389,13 @@ int plan_upload(mi_rtj_plan* p) {
   return MI_RTJ_OK;
 }
 
-int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
+// what: the index kernels (kLaunchIndex), k_decode (kLaunchDecode) or both.  A session whose packets are indexed in
+// groups queues the index of a group once and then k_decode packet by packet (dframe = the packet's place in the group,
+// dcount = 1, d_out = its picture): a packet's unchanged blocks come from its predecessor's picture, so the pictures of
+// a group cannot be made by one launch.
+enum { kLaunchIndex = 1, kLaunchDecode = 2, kLaunchAll = 3 };
+int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out, int what = kLaunchAll, uint32_t dframe = 0,
+                int dcount = -1) {
   mi_rtj_ctx* c = p->ctx;
   const uint8_t* st = (const uint8_t*)d_stream;
   // The index kernels run on `is`, k_decode on the instance's stream.  Plans have them equal; a session gives its slots
@@ -413,87 +433,89 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
     return MI_RTJ_OK;
   };
   int rc;
-  if (p->serial_index) {
-    if ((rc = begin(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
-    hipLaunchKernelGGL(k_index_walk, dim3(p->n), dim3(64), 0, is, p->d_frames, st, c->d_lut, blk);
-    if ((rc = end(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
-  } else {
-    const uint32_t *todo = nullptr, *ntodo = nullptr;
-    unsigned rows = (unsigned)p->n;  // grid rows of the exact kernels: one per packet, or a few that loop over the to-do list
-    const bool spec = p->spec;
-    // noisy content defeats the speculation; a plan that sees every packet refused twice in a row goes
-    // without it for kSpecPauseLaunches launches.  The policy lives on the device (k_spec_policy), so it
-    // also works when launches are queued faster than they run.
-    const bool no_policy = p->spec_mode == 1 || p->spec_mode == 3 || p->spec_mode == 4;  // always speculate: short (1), long (3) or very long (4) lead
-    uint32_t* const state = no_policy ? nullptr : p->d_spec_state;
-    if (spec) {
-      ntodo = p->d_spec_todo;
-      todo = p->d_spec_todo + 1;
-      rows = std::min<unsigned>(rows, kSpecFallbackRows);
-      if ((rc = begin(MI_RTJ_K_SPEC_WALK)) != MI_RTJ_OK) return rc;
-      // The walkers zero the launch's lists themselves (SpecReset).  With a policy ONE dispatch runs the form the
-      // policy's state names (or returns at once while the speculation is paused); without (MI_RTJ_SPEC = 1 / 3 / 4:
-      // tests) the form asked for.
-      const dim3 wgrid((unsigned)((p->n_spec + 63) / 64));
-      const SpecReset rs{p->d_spec_nfix, p->d_spec_todo, p->d_spec_flag};
-#define MIRTJ_WALK_ARGS p->d_frames, p->d_spec_chunks, (uint32_t)p->n_spec, st, c->d_lut, p->d_spec_rec, p->d_spec_nrec, p->d_spec_wstart, p->d_spec_hand, rs
-      if (state) {
-        if (p->one_block_type) hipLaunchKernelGGL((k_spec_walk_any<false>), wgrid, dim3(64), 0, is, MIRTJ_WALK_ARGS, state);
-        else hipLaunchKernelGGL((k_spec_walk_any<true>), wgrid, dim3(64), 0, is, MIRTJ_WALK_ARGS, state);
-      } else if (p->one_block_type) {
-        if (p->spec_mode == 1) hipLaunchKernelGGL((k_spec_walk<false, kSpecLead>), wgrid, dim3(64), 0, is, MIRTJ_WALK_ARGS);
-        if (p->spec_mode == 3) hipLaunchKernelGGL((k_spec_walk<false, kSpecLeadLong>), wgrid, dim3(64), 0, is, MIRTJ_WALK_ARGS);
-        if (p->spec_mode == 4) hipLaunchKernelGGL((k_spec_walk<false, kSpecLeadVery>), wgrid, dim3(64), 0, is, MIRTJ_WALK_ARGS);
-      } else {
-        if (p->spec_mode == 1) hipLaunchKernelGGL((k_spec_walk<true, kSpecLead>), wgrid, dim3(64), 0, is, MIRTJ_WALK_ARGS);
-        if (p->spec_mode == 3) hipLaunchKernelGGL((k_spec_walk<true, kSpecLeadLong>), wgrid, dim3(64), 0, is, MIRTJ_WALK_ARGS);
-        if (p->spec_mode == 4) hipLaunchKernelGGL((k_spec_walk<true, kSpecLeadVery>), wgrid, dim3(64), 0, is, MIRTJ_WALK_ARGS);
-      }
-#undef MIRTJ_WALK_ARGS
-      if ((rc = end(MI_RTJ_K_SPEC_WALK)) != MI_RTJ_OK) return rc;
-      if ((rc = begin(MI_RTJ_K_SPEC_VERIFY)) != MI_RTJ_OK) return rc;
-      // first pass; walkers that had not fallen into step are walked again from a known block start; second
-      // pass over the packets concerned (both return at once when there is nothing to repair)
-      hipLaunchKernelGGL(k_spec_verify, dim3(p->n), dim3(kSpecVerThreads), 0, is, p->d_frames, p->d_spec_base, c->d_lut,
-                         p->d_spec_rec, p->d_spec_nrec, blk, p->d_spec_ok, p->d_spec_todo + 1, p->d_spec_todo, state,
-                         p->d_spec_wstart, p->d_spec_hand, p->d_spec_fix, p->d_spec_nfix, p->d_spec_flag, 1);
-      hipLaunchKernelGGL(k_spec_repair, dim3(kSpecRepairGrid), dim3(64), 0, is, p->d_frames, p->d_spec_chunks, st,
-                         c->d_lut, p->d_spec_rec, p->d_spec_nrec, p->d_spec_wstart, p->d_spec_hand, p->d_spec_fix, p->d_spec_nfix,
-                         p->d_spec_flag, (uint32_t)p->n_spec, state);
-      hipLaunchKernelGGL(k_spec_verify, dim3(p->n), dim3(kSpecVerThreads), 0, is, p->d_frames, p->d_spec_base, c->d_lut,
-                         p->d_spec_rec, p->d_spec_nrec, blk, p->d_spec_ok, p->d_spec_todo + 1, p->d_spec_todo, state,
-                         p->d_spec_wstart, p->d_spec_hand, p->d_spec_fix, p->d_spec_nfix, p->d_spec_flag, 2);
-      if ((rc = end(MI_RTJ_K_SPEC_VERIFY)) != MI_RTJ_OK) return rc;
-      if (state) hipLaunchKernelGGL(k_spec_policy, dim3(1), dim3(256), 0, is, (uint32_t)p->n, (uint32_t)p->n_spec, p->d_spec_todo, p->d_spec_nfix, state);
-    }
-    if ((rc = begin(MI_RTJ_K_SUMMARIZE)) != MI_RTJ_OK) return rc;
-    if (todo) {
-      if (p->one_block_type)
-        hipLaunchKernelGGL(k_index_summarize_todo<1>, dim3(p->max_chunks, rows), dim3(kSumThreads), 0, is,
-                           p->d_frames, st, c->d_lut, p->d_summary, p->d_lentab, todo, ntodo);
-      else
-        hipLaunchKernelGGL(k_index_summarize_todo<2>, dim3(p->max_chunks, rows), dim3(kSumThreads), 0, is,
-                           p->d_frames, st, c->d_lut, p->d_summary, p->d_lentab, todo, ntodo);
-    } else if (p->one_block_type) {
-      hipLaunchKernelGGL(k_index_summarize<1>, dim3(p->max_chunks, rows), dim3(kSumThreads), 0, is, p->d_frames,
-                         st, c->d_lut, p->d_summary, p->d_lentab);
+  if (what & kLaunchIndex) {
+    if (p->serial_index) {
+      if ((rc = begin(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
+      hipLaunchKernelGGL(k_index_walk, dim3(p->n), dim3(64), 0, is, p->d_frames, st, c->d_lut, blk);
+      if ((rc = end(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
     } else {
-      hipLaunchKernelGGL(k_index_summarize<2>, dim3(p->max_chunks, rows), dim3(kSumThreads), 0, is, p->d_frames,
-                         st, c->d_lut, p->d_summary, p->d_lentab);
+      const uint32_t *todo = nullptr, *ntodo = nullptr;
+      unsigned rows = (unsigned)p->n;  // grid rows of the exact kernels: one per packet, or a few that loop over the to-do list
+      const bool spec = p->spec;
+      // noisy content defeats the speculation; a plan that sees every packet refused twice in a row goes
+      // without it for kSpecPauseLaunches launches.  The policy lives on the device (k_spec_policy), so it
+      // also works when launches are queued faster than they run.
+      const bool no_policy = p->spec_mode == 1 || p->spec_mode == 3 || p->spec_mode == 4;  // always speculate: short (1), long (3) or very long (4) lead
+      uint32_t* const state = no_policy ? nullptr : p->d_spec_state;
+      if (spec) {
+        ntodo = p->d_spec_todo;
+        todo = p->d_spec_todo + 1;
+        rows = std::min<unsigned>(rows, kSpecFallbackRows);
+        if ((rc = begin(MI_RTJ_K_SPEC_WALK)) != MI_RTJ_OK) return rc;
+        // The walkers zero the launch's lists themselves (SpecReset).  With a policy ONE dispatch runs the form the
+        // policy's state names (or returns at once while the speculation is paused); without (MI_RTJ_SPEC = 1 / 3 / 4:
+        // tests) the form asked for.
+        const dim3 wgrid((unsigned)((p->n_spec + 63) / 64));
+        const SpecReset rs{p->d_spec_nfix, p->d_spec_todo, p->d_spec_flag};
+#define MIRTJ_WALK_ARGS p->d_frames, p->d_spec_chunks, (uint32_t)p->n_spec, st, c->d_lut, p->d_spec_rec, p->d_spec_nrec, p->d_spec_wstart, p->d_spec_hand, rs
+        if (state) {
+          if (p->one_block_type) hipLaunchKernelGGL((k_spec_walk_any<false>), wgrid, dim3(64), 0, is, MIRTJ_WALK_ARGS, state);
+          else hipLaunchKernelGGL((k_spec_walk_any<true>), wgrid, dim3(64), 0, is, MIRTJ_WALK_ARGS, state);
+        } else if (p->one_block_type) {
+          if (p->spec_mode == 1) hipLaunchKernelGGL((k_spec_walk<false, kSpecLead>), wgrid, dim3(64), 0, is, MIRTJ_WALK_ARGS);
+          if (p->spec_mode == 3) hipLaunchKernelGGL((k_spec_walk<false, kSpecLeadLong>), wgrid, dim3(64), 0, is, MIRTJ_WALK_ARGS);
+          if (p->spec_mode == 4) hipLaunchKernelGGL((k_spec_walk<false, kSpecLeadVery>), wgrid, dim3(64), 0, is, MIRTJ_WALK_ARGS);
+        } else {
+          if (p->spec_mode == 1) hipLaunchKernelGGL((k_spec_walk<true, kSpecLead>), wgrid, dim3(64), 0, is, MIRTJ_WALK_ARGS);
+          if (p->spec_mode == 3) hipLaunchKernelGGL((k_spec_walk<true, kSpecLeadLong>), wgrid, dim3(64), 0, is, MIRTJ_WALK_ARGS);
+          if (p->spec_mode == 4) hipLaunchKernelGGL((k_spec_walk<true, kSpecLeadVery>), wgrid, dim3(64), 0, is, MIRTJ_WALK_ARGS);
+        }
+#undef MIRTJ_WALK_ARGS
+        if ((rc = end(MI_RTJ_K_SPEC_WALK)) != MI_RTJ_OK) return rc;
+        if ((rc = begin(MI_RTJ_K_SPEC_VERIFY)) != MI_RTJ_OK) return rc;
+        // first pass; walkers that had not fallen into step are walked again from a known block start; second
+        // pass over the packets concerned (both return at once when there is nothing to repair)
+        hipLaunchKernelGGL(k_spec_verify, dim3(p->n), dim3(kSpecVerThreads), 0, is, p->d_frames, p->d_spec_base, c->d_lut,
+                           p->d_spec_rec, p->d_spec_nrec, blk, p->d_spec_ok, p->d_spec_todo + 1, p->d_spec_todo, state,
+                           p->d_spec_wstart, p->d_spec_hand, p->d_spec_fix, p->d_spec_nfix, p->d_spec_flag, 1);
+        hipLaunchKernelGGL(k_spec_repair, dim3(kSpecRepairGrid), dim3(64), 0, is, p->d_frames, p->d_spec_chunks, st,
+                           c->d_lut, p->d_spec_rec, p->d_spec_nrec, p->d_spec_wstart, p->d_spec_hand, p->d_spec_fix, p->d_spec_nfix,
+                           p->d_spec_flag, (uint32_t)p->n_spec, state);
+        hipLaunchKernelGGL(k_spec_verify, dim3(p->n), dim3(kSpecVerThreads), 0, is, p->d_frames, p->d_spec_base, c->d_lut,
+                           p->d_spec_rec, p->d_spec_nrec, blk, p->d_spec_ok, p->d_spec_todo + 1, p->d_spec_todo, state,
+                           p->d_spec_wstart, p->d_spec_hand, p->d_spec_fix, p->d_spec_nfix, p->d_spec_flag, 2);
+        if ((rc = end(MI_RTJ_K_SPEC_VERIFY)) != MI_RTJ_OK) return rc;
+        if (state) hipLaunchKernelGGL(k_spec_policy, dim3(1), dim3(256), 0, is, (uint32_t)p->n, (uint32_t)p->n_spec, p->d_spec_todo, p->d_spec_nfix, state);
+      }
+      if ((rc = begin(MI_RTJ_K_SUMMARIZE)) != MI_RTJ_OK) return rc;
+      if (todo) {
+        if (p->one_block_type)
+          hipLaunchKernelGGL(k_index_summarize_todo<1>, dim3(p->max_chunks, rows), dim3(kSumThreads), 0, is,
+                             p->d_frames, st, c->d_lut, p->d_summary, p->d_lentab, todo, ntodo);
+        else
+          hipLaunchKernelGGL(k_index_summarize_todo<2>, dim3(p->max_chunks, rows), dim3(kSumThreads), 0, is,
+                             p->d_frames, st, c->d_lut, p->d_summary, p->d_lentab, todo, ntodo);
+      } else if (p->one_block_type) {
+        hipLaunchKernelGGL(k_index_summarize<1>, dim3(p->max_chunks, rows), dim3(kSumThreads), 0, is, p->d_frames,
+                           st, c->d_lut, p->d_summary, p->d_lentab);
+      } else {
+        hipLaunchKernelGGL(k_index_summarize<2>, dim3(p->max_chunks, rows), dim3(kSumThreads), 0, is, p->d_frames,
+                           st, c->d_lut, p->d_summary, p->d_lentab);
+      }
+      if ((rc = end(MI_RTJ_K_SUMMARIZE)) != MI_RTJ_OK) return rc;
+      if ((rc = begin(MI_RTJ_K_RESOLVE)) != MI_RTJ_OK) return rc;
+      hipLaunchKernelGGL(k_index_resolve, dim3(todo ? std::min<unsigned>((unsigned)p->n, 1024u) : rows), dim3(256), 0, is, p->d_frames, p->d_summary,
+                         p->d_chunk_pos, p->d_chunk_mb, todo, ntodo);
+      if ((rc = end(MI_RTJ_K_RESOLVE)) != MI_RTJ_OK) return rc;
+      if ((rc = begin(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
+      if (p->emit_walk)
+        hipLaunchKernelGGL(k_index_emit_walk, dim3(p->max_chunks, p->n), dim3(64), 0, is, p->d_frames, st,
+                           c->d_lut, p->d_chunk_pos, p->d_chunk_mb, blk);
+      else
+        hipLaunchKernelGGL(k_index_emit, dim3(p->max_chunks, rows), dim3(kEmitThreads), 0, is, p->d_frames,
+                           p->d_lentab, p->d_chunk_pos, p->d_chunk_mb, blk, todo, ntodo);
+      if ((rc = end(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
     }
-    if ((rc = end(MI_RTJ_K_SUMMARIZE)) != MI_RTJ_OK) return rc;
-    if ((rc = begin(MI_RTJ_K_RESOLVE)) != MI_RTJ_OK) return rc;
-    hipLaunchKernelGGL(k_index_resolve, dim3(todo ? std::min<unsigned>((unsigned)p->n, 1024u) : rows), dim3(256), 0, is, p->d_frames, p->d_summary,
-                       p->d_chunk_pos, p->d_chunk_mb, todo, ntodo);
-    if ((rc = end(MI_RTJ_K_RESOLVE)) != MI_RTJ_OK) return rc;
-    if ((rc = begin(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
-    if (p->emit_walk)
-      hipLaunchKernelGGL(k_index_emit_walk, dim3(p->max_chunks, p->n), dim3(64), 0, is, p->d_frames, st,
-                         c->d_lut, p->d_chunk_pos, p->d_chunk_mb, blk);
-    else
-      hipLaunchKernelGGL(k_index_emit, dim3(p->max_chunks, rows), dim3(kEmitThreads), 0, is, p->d_frames,
-                         p->d_lentab, p->d_chunk_pos, p->d_chunk_mb, blk, todo, ntodo);
-    if ((rc = end(MI_RTJ_K_EMIT)) != MI_RTJ_OK) return rc;
   }
   if (is != ds) {  // k_decode waits for the index (and, through it, for the packet's copy in)
     if (!p->e_idx) HIPCHK(c, hipEventCreateWithFlags(&p->e_idx, hipEventDisableTiming));
@@ -502,33 +524,40 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out) {
     prev = nullptr;  // (profiling) k_decode's start is not the end of a kernel on another stream
   }
   cur = ds;
+  if (!(what & kLaunchDecode)) {
+    HIPCHK(c, hipGetLastError());
+    return MI_RTJ_OK;
+  }
+  if (what != kLaunchAll) prev = nullptr;  // (profiling) k_decode's start is not the end of the kernel queued before it
+  const unsigned drows = dcount < 0 ? (unsigned)p->n : (unsigned)dcount;
+  const FrameDev* const dfr = p->d_frames + dframe;
   if ((rc = begin(MI_RTJ_K_DECODE)) != MI_RTJ_OK) return rc;
   // the A/B override is honoured only where it still covers every group
   // a wave per (slot, part) or, in batches that still make enough waves that way, per slot: the wave then takes the
   // three parts of each of its groups in turn and the group's stream bytes cross the fabric once (kernel header)
   const uint32_t span = p->rotate >= 0 ? (p->rotate ? 3u : 1u)
-                        : (uint64_t)p->n * p->max_groups >= (uint64_t)kDecRotateMinGroups ? 3u : 1u;
+                        : (uint64_t)drows * p->max_groups >= (uint64_t)kDecRotateMinGroups ? 3u : 1u;
   const uint32_t dslots = p->dec_slots && p->dec_slots * (uint32_t)kDecIters >= p->max_groups
                               ? p->dec_slots
-                              : decode_slots(p->max_groups, (uint32_t)p->n, span);
+                              : decode_slots(p->max_groups, (uint32_t)drows, span);
   {
-    const dim3 grid(span == 3u ? dslots : dslots * 3u, p->n), block(kDecThreads);
+    const dim3 grid(span == 3u ? dslots : dslots * 3u, drows), block(kDecThreads);
     uint8_t* const out8 = (uint8_t*)d_out;
     // four instantiations: (a wave takes all three parts of its groups | one part) x (unchanged blocks stay | are
     // fetched from the previous packet's picture); a launch runs the one that carries nothing else
     if (span == 3u) {
       if (p->prev_pic)
-        hipLaunchKernelGGL((k_decode<true, true>), grid, block, 0, ds, p->d_frames, st, c->d_lut, blk, out8,
+        hipLaunchKernelGGL((k_decode<true, true>), grid, block, 0, ds, dfr, st, c->d_lut, blk, out8,
                            p->prev_pic);
       else
-        hipLaunchKernelGGL((k_decode<true, false>), grid, block, 0, ds, p->d_frames, st, c->d_lut, blk, out8,
+        hipLaunchKernelGGL((k_decode<true, false>), grid, block, 0, ds, dfr, st, c->d_lut, blk, out8,
                            (const uint8_t*)nullptr);
     } else {
       if (p->prev_pic)
-        hipLaunchKernelGGL((k_decode<false, true>), grid, block, 0, ds, p->d_frames, st, c->d_lut, blk, out8,
+        hipLaunchKernelGGL((k_decode<false, true>), grid, block, 0, ds, dfr, st, c->d_lut, blk, out8,
                            p->prev_pic);
       else
-        hipLaunchKernelGGL((k_decode<false, false>), grid, block, 0, ds, p->d_frames, st, c->d_lut, blk,
+        hipLaunchKernelGGL((k_decode<false, false>), grid, block, 0, ds, dfr, st, c->d_lut, blk,
                            out8, (const uint8_t*)nullptr);
     }
   }
@@ -1121,6 +1150,103 @@ int pipe_issue(mi_rtj_pipe* q, PipeSlot& sl) {
   return MI_RTJ_OK;
 }
 
+// ---- index groups: copy in now, kernels when the group is complete ----
+int pipe_stage(mi_rtj_pipe* q, PipeSlot& sl) {
+  mi_rtj_ctx* c = q->ctx;
+  if (!(q->exp_skip & 4))
+    HIPCHK(c, hipMemcpyAsync(sl.d_stage, sl.h_stage, sizeof(FrameDev) + sl.len, hipMemcpyHostToDevice, q->s_in));
+  sl.staged = 1;
+  sl.out_state = 0;
+  q->nstaged++;
+  return MI_RTJ_OK;
+}
+
+// queue the kernels of the `count` staged slots first .. first + count - 1 (one aligned group or a part of one)
+int pipe_issue_group(mi_rtj_pipe* q, int first, int count) {
+  mi_rtj_ctx* c = q->ctx;
+  mi_rtj_plan* p = q->gplan[first / q->igroup];
+  p->n = count;
+  p->h_frames.resize((size_t)count);
+  uint64_t nidx = 0;
+  uint32_t max_groups = 0;
+  p->n_blocks = 0;
+  for (int j = 0; j < count; j++) {
+    FrameDev& f = q->slot[first + j].fd;
+    f.blk_base = (uint32_t)nidx;
+    nidx += (((uint64_t)f.nmb * 6 + 1) + 63) & ~63ull;
+    p->n_blocks += (uint64_t)f.nmb * 6;
+    max_groups = std::max(max_groups, (f.nmb + kMbPerGroup - 1) / kMbPerGroup);
+    p->h_frames[(size_t)j] = f;
+  }
+  p->max_groups = max_groups;
+  if (nidx > p->n_index) {
+    if (p->d_blkoff) {
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      (void)hipFree(p->d_blkoff);
+      p->d_blkoff = nullptr;
+      p->n_index = 0;
+    }
+    const uint64_t cap = nidx / (uint64_t)count * (uint64_t)q->igroup;  // room for a whole group of such pictures
+    HIPCHK(c, hipMalloc((void**)&p->d_blkoff, sizeof(uint32_t) * std::max(cap, nidx)));
+    p->n_index = std::max(cap, nidx);
+  }
+  {
+    const int rc = plan_alloc_chunks(p);  // chunk bases of the group's packets; allocates only when the group outgrows its buffers
+    if (rc != MI_RTJ_OK) return rc;
+  }
+  // the descriptors follow the packets on the copy-in stream; the kernels wait for both
+  for (int j = 0; j < count; j++) q->h_desc[first + j] = p->h_frames[(size_t)j];
+  HIPCHK(c, hipMemcpyAsync(q->d_desc + first, q->h_desc + first, sizeof(FrameDev) * (size_t)count, hipMemcpyHostToDevice, q->s_in));
+  PipeSlot& lastsl = q->slot[first + count - 1];
+  HIPCHK(c, hipEventRecord(lastsl.e_in, q->s_in));
+  HIPCHK(c, hipStreamWaitEvent(c->stream, lastsl.e_in, 0));
+  p->d_frames = q->d_desc + first;
+  // (data_off of these descriptors is the packet's device ADDRESS: the kernels add it to a null stream base)
+  if (!(q->exp_skip & 2)) {
+    p->prev_pic = nullptr;
+    const int rc = plan_launch(p, nullptr, nullptr, kLaunchIndex);
+    if (rc != MI_RTJ_OK) return rc;
+  }
+  for (int j = 0; j < count; j++) {
+    PipeSlot& sl = q->slot[first + j];
+    if (!(q->exp_skip & 2)) {
+      p->prev_pic = sl.prev;
+      const int rc = plan_launch(p, nullptr, sl.d_pic, kLaunchDecode, (uint32_t)j, 1);
+      if (rc != MI_RTJ_OK) return rc;
+    }
+    HIPCHK(c, hipEventRecord(sl.e_dec, c->stream));
+    sl.staged = 0;
+    sl.out_state = 1;
+    q->nstaged--;
+    if ((first + j) % q->group == q->group - 1) {
+      const int rc = pipe_copy_out(q, first + j);
+      if (rc != MI_RTJ_OK) return rc;
+    }
+  }
+  return MI_RTJ_OK;
+}
+
+// the staged slots are the last q->nstaged submitted ones; queue their kernels
+int pipe_issue_staged(mi_rtj_pipe* q) {
+  if (q->nstaged <= 0) return MI_RTJ_OK;
+  const int count = q->nstaged;
+  const int last = (q->head + q->count - 1 + q->depth) % q->depth;
+  const int first = last - (count - 1);  // a group never wraps: the depth is a multiple of the group size
+  const int rc = pipe_issue_group(q, first, count);
+  if (rc != MI_RTJ_OK) {  // what could not be queued yields no pictures
+    for (int j = 0; j < count; j++) {
+      PipeSlot& sl = q->slot[first + j];
+      if (sl.staged) {
+        sl.staged = 0;
+        sl.rc = rc;
+        sl.err = q->ctx->err;
+      }
+    }
+    q->nstaged = 0;
+  }
+  return rc;
+}
+
 void pipe_worker(mi_rtj_pipe* q) {
   (void)hipSetDevice(q->ctx->device);
   for (;;) {
@@ -1180,15 +1306,24 @@ mi_rtj_pipe* mi_rtj_pipe_create(mi_rtj_ctx* c, int depth, int max_w, int max_h) 
   }
   {
     const char* og = getenv("MI_RTJ_OUT_GROUP");
-    const int g = og ? atoi(og) : 2;
+    // fours from twelve packets in flight on (three groups: one being copied, one queued behind it, one being filled):
+    // 16.0-16.2 K pictures per second at 1080p against 15.0 K in pairs, 4.36 K at 4K against 4.26 K (the link gives
+    // 4.39 K); with two groups of four the copy engine idles while the caller refills one (9.9 K)
+    const int g = og ? atoi(og) : depth >= 12 ? 4 : 2;
     // (groups need every picture to have the session's size, and the caller's thread to be the one that queues copies)
     const char* th0 = getenv("MI_RTJ_PIPE_THREAD");
     q->group = (max_w > 0 && max_h > 0 && !(th0 && atoi(th0) != 0) && (g == 2 || g == 4)) ? g : 1;
-    if (q->group > 1) {
-      q->depth = depth = (depth + q->group - 1) / q->group * q->group;
+    // the index is built in groups too, by default the same ones (needs the same things: one coded size, the
+    // caller's thread queuing the work); MI_RTJ_IDX_GROUP = 1 is the packet-by-packet index of rounds 2 and 3
+    const char* ig = getenv("MI_RTJ_IDX_GROUP");
+    const int igv = ig ? atoi(ig) : q->group;
+    q->igroup = (max_w > 0 && max_h > 0 && !(th0 && atoi(th0) != 0) && (igv == 2 || igv == 4)) ? igv : 1;
+    const int unit = std::max(q->group, q->igroup);  // (1, 2 or 4 each: the larger is a multiple of the other)
+    if (unit > 1) {
+      q->depth = depth = (depth + unit - 1) / unit * unit;
       q->slot.resize(depth);
-      q->grp_fsz = (size_t)max_w * max_h * 3 / 2;
     }
+    if (q->group > 1) q->grp_fsz = (size_t)max_w * max_h * 3 / 2;
   }
   bool ok = hipStreamCreateWithFlags(&q->s_in, hipStreamNonBlocking) == hipSuccess;
   {
@@ -1213,6 +1348,20 @@ mi_rtj_pipe* mi_rtj_pipe_create(mi_rtj_ctx* c, int depth, int max_w, int max_h) 
     ok = ok && hipEventCreateWithFlags(&sl.e_in, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&sl.e_dec, hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&sl.e_out, hipEventDisableTiming) == hipSuccess;
+  }
+  if (ok && q->igroup > 1) {  // one plan per index group, the descriptors of all slots in one array
+    ok = hipHostMalloc((void**)&q->h_desc, sizeof(FrameDev) * (size_t)depth, hipHostMallocDefault) == hipSuccess &&
+         hipMalloc((void**)&q->d_desc, sizeof(FrameDev) * (size_t)depth) == hipSuccess;
+    q->gplan.assign((size_t)(depth / q->igroup), nullptr);
+    for (auto& gp : q->gplan) {
+      gp = new mi_rtj_plan();
+      gp->ctx = c;
+      gp->n = q->igroup;
+      gp->spec_mode = 0;  // a handful of packets per launch: the exact index
+      gp->serial_index = mode && strcmp(mode, "serial") == 0;
+      gp->emit_walk = em && strcmp(em, "walk") == 0;
+      gp->h_frames.resize((size_t)q->igroup);
+    }
   }
   if (ok && q->group > 1) {  // the group buffers: `group` pictures side by side, on the device and in pinned host memory
     const int ng = depth / q->group;
@@ -1281,6 +1430,13 @@ void mi_rtj_pipe_destroy(mi_rtj_pipe* q) {
     if (sl.e_dec) (void)hipEventDestroy(sl.e_dec);
     if (sl.e_out) (void)hipEventDestroy(sl.e_out);
   }
+  for (mi_rtj_plan* gp : q->gplan)
+    if (gp) {
+      gp->d_frames = nullptr;  // points into d_desc, not owned by the plan
+      mi_rtj_plan_destroy(gp);
+    }
+  if (q->h_desc) (void)hipHostFree(q->h_desc);
+  if (q->d_desc) (void)hipFree(q->d_desc);
   for (uint8_t* g : q->d_grp)
     if (g) (void)hipFree(g);
   for (uint8_t* g : q->h_grp)
@@ -1365,22 +1521,29 @@ int mi_rtj_pipe_submit(mi_rtj_pipe* q, const uint8_t* pkt, size_t len, uint64_t 
     sl.stage_cap = need * 2;
   }
   const uint64_t nidx = (((uint64_t)f.nmb * 6 + 1) + 63) & ~63ull;
-  if (nidx > p->n_index) {
-    if (p->d_blkoff) (void)hipFree(p->d_blkoff);
-    p->d_blkoff = nullptr;
-    p->n_index = 0;
-    HIPCHK(c, hipMalloc((void**)&p->d_blkoff, sizeof(uint32_t) * nidx));
-    p->n_index = nidx;
-  }
-  p->n_blocks = (uint64_t)f.nmb * 6;
-  p->max_groups = (f.nmb + kMbPerGroup - 1) / kMbPerGroup;
-  {
+  const bool grouped = q->igroup > 1;  // the index of this packet is built with its group's (pipe_issue_group)
+  if (!grouped) {
+    if (nidx > p->n_index) {
+      if (p->d_blkoff) (void)hipFree(p->d_blkoff);
+      p->d_blkoff = nullptr;
+      p->n_index = 0;
+      HIPCHK(c, hipMalloc((void**)&p->d_blkoff, sizeof(uint32_t) * nidx));
+      p->n_index = nidx;
+    }
+    p->n_blocks = (uint64_t)f.nmb * 6;
+    p->max_groups = (f.nmb + kMbPerGroup - 1) / kMbPerGroup;
     const int rc2 = plan_alloc_chunks(p);  // sets the chunk bases in the descriptor; allocates only when it grows
     if (rc2 != MI_RTJ_OK) return rc2;
   }
   // descriptor and packet travel together: one copy in, on its own stream
   FrameDev& fd = p->h_frames[0];  // plan_alloc_chunks has set its chunk bases
   fd.data_off = sizeof(FrameDev) + MI_RTJ_HEADER_SIZE;
+  if (grouped) {
+    // the kernels of a group get a null stream base: data_off is the device address of the packet's first data byte
+    // (the packets of a group lie in their slots' own buffers); block and chunk bases are set when the group is queued
+    fd.data_off = (uint64_t)(uintptr_t)sl.d_stage + sizeof(FrameDev) + MI_RTJ_HEADER_SIZE;
+    sl.fd = fd;
+  }
   const double ts0 = q->stats ? host_now() : 0.0;
   memcpy(sl.h_stage, &fd, sizeof(FrameDev));
   memcpy(sl.h_stage + sizeof(FrameDev), pkt, len);
@@ -1399,7 +1562,14 @@ int mi_rtj_pipe_submit(mi_rtj_pipe* q, const uint8_t* pkt, size_t len, uint64_t 
   q->submitted++;
   if (!q->threaded) {
     const double ti0 = q->stats ? host_now() : 0.0;
-    sl.rc = pipe_issue(q, sl);
+    if (grouped) {
+      sl.rc = pipe_stage(q, sl);
+      // the group's last slot: queue the kernels of the whole group.  Should that fail, the packets are in all the
+      // same; their slots carry the error and yield no pictures (mi_rtj_pipe_next reports it)
+      if (sl.rc == MI_RTJ_OK && idx % q->igroup == q->igroup - 1) (void)pipe_issue_staged(q);
+    } else {
+      sl.rc = pipe_issue(q, sl);
+    }
     if (q->stats) q->t_issue += host_now() - ti0;
     sl.issued = 1;
     if (sl.rc != MI_RTJ_OK) {  // undo: the packet never went in, its predecessor is still the last picture
@@ -1433,7 +1603,12 @@ int mi_rtj_pipe_next(mi_rtj_pipe* q, const uint8_t* planes[3], int strides[3], i
     std::unique_lock<std::mutex> lk(q->mu);
     q->cv_done.wait(lk, [&] { return sl.issued != 0; });
   }
-  if (sl.rc != MI_RTJ_OK) {  // queuing this packet failed on the worker: it yields no picture
+  if (sl.staged) {  // its index group is not complete: the kernels of what is staged are queued now
+    const double ti0 = q->stats ? host_now() : 0.0;
+    (void)pipe_issue_staged(q);  // (a failure is in the slots' rc)
+    if (q->stats) q->t_issue += host_now() - ti0;
+  }
+  if (sl.rc != MI_RTJ_OK) {  // queuing this packet failed (on the worker, or with its group): it yields no picture
     const int rc = sl.rc;
     if (!sl.err.empty()) c->err = sl.err;
     q->head = (q->head + 1) % q->depth;
@@ -1479,6 +1654,7 @@ int mi_rtj_pipe_profile(mi_rtj_pipe* q, int enable) {
   const int rc = mi_rtj_pipe_flush(q);
   if (rc != MI_RTJ_OK) return rc;
   for (auto& sl : q->slot) mi_rtj_plan_profile(sl.plan, enable);
+  for (mi_rtj_plan* gp : q->gplan) mi_rtj_plan_profile(gp, enable);
   return MI_RTJ_OK;
 }
 
@@ -1487,10 +1663,13 @@ int mi_rtj_pipe_times(mi_rtj_pipe* q, float ms[MI_RTJ_NUM_KERNELS], int* launche
   pipe_drain_jobs(q);
   int total = 0;
   for (int k = 0; k < MI_RTJ_NUM_KERNELS; k++) ms[k] = 0.f;
-  for (auto& sl : q->slot) {
+  std::vector<mi_rtj_plan*> plans;
+  for (auto& sl : q->slot) plans.push_back(sl.plan);
+  for (mi_rtj_plan* gp : q->gplan) plans.push_back(gp);
+  for (mi_rtj_plan* pl : plans) {  // (launches = k_decode launches = packets: a group's index kernels count once)
     float one[MI_RTJ_NUM_KERNELS];
     int n = 0;
-    const int rc = mi_rtj_plan_times(sl.plan, one, &n);
+    const int rc = mi_rtj_plan_times(pl, one, &n);
     if (rc != MI_RTJ_OK) return rc;
     for (int k = 0; k < MI_RTJ_NUM_KERNELS; k++) ms[k] += one[k];
     total += n;
@@ -1515,7 +1694,11 @@ int mi_rtj_pipe_flush(mi_rtj_pipe* q) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (q->s_idx) HIPCHK(c, hipStreamSynchronize(q->s_idx));
   for (int i = 0; i < q->n_out; i++) HIPCHK(c, hipStreamSynchronize(q->s_out[i]));
-  for (auto& sl : q->slot) sl.out_state = 0;
+  for (auto& sl : q->slot) {
+    sl.out_state = 0;
+    sl.staged = 0;  // (a packet copied in and never indexed is simply forgotten)
+  }
+  q->nstaged = 0;
   q->head = (q->head + q->count) % q->depth;
   q->count = 0;
   q->lent = -1;

@@ -60,7 +60,7 @@
 #endif
 #ifdef MI_RTJ_PIPELINE
 #define MI_RTJ_MAX_DEPTH 64
-#define MI_RTJ_DEFAULT_DEPTH 6
+#define MI_RTJ_DEFAULT_DEPTH 12 /* three groups of four: pictures leave (and packets are indexed) four at a time from 12 on */
 #endif
 
 #define MI_RTJ_OPT_DEVICE "mi355x-device" /* int: HIP device ordinal */

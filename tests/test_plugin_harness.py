@@ -95,12 +95,13 @@ def test_wrapper_decodes_like_the_reference_wrapper(tmp_path, w, h, iw, ih, key_
 PIPE = HARNESS_COPY + "_pipe"
 
 
-def run_pipe(tmp_path, pkts, iw, ih, *opts, depth=None):
+def run_pipe(tmp_path, pkts, iw, ih, *opts, depth=None, extra_env=None):
     pk, out = tmp_path / "p.bin", tmp_path / "o.bin"
     write_packets(pk, pkts)
     env = dict(os.environ)
     if depth:
         env["MI_RTJ_DEPTH"] = str(depth)
+    env.update(extra_env or {})
     r = subprocess.run([PIPE, str(pk), str(iw), str(ih), str(out)] + list(opts), capture_output=True, text=True, env=env)
     fsz = iw * ih + 2 * ((iw + 1) // 2) * ((ih + 1) // 2)
     raw = np.fromfile(out, dtype=np.uint8) if os.path.exists(out) else np.zeros(0, np.uint8)
@@ -122,6 +123,32 @@ def test_pipelined_decoder_hands_out_the_same_pictures_in_order(tmp_path, w, h, 
     r, recs = run_pipe(tmp_path, pkts, iw, ih, depth=depth)
     assert r.returncode == 0, r.stderr
     want = expected_stream(pkts, w, h, iw, ih, 0)
+    assert len(recs) == len(want)
+    for i, ((got, pts), (planes, wpts)) in enumerate(zip(recs, want)):
+        assert np.array_equal(got, planes), i
+        assert pts == wpts
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idx_group,out_group,depth", [(1, 1, 3), (1, 2, 4), (2, 1, 6), (2, 2, 6), (4, 2, 6), (4, 4, 8), (2, 4, 5)])
+@pytest.mark.parametrize("seek", [False, True])
+def test_index_and_copy_groups_of_any_size_hand_out_the_same_pictures(tmp_path, idx_group, out_group, depth, seek):
+    """the packets of a session are indexed in groups (one launch of the index kernels per group, k_decode packet by
+    packet: unchanged blocks come from the predecessor's picture) and their pictures copied out in groups; every
+    combination gives the pictures of the packet-by-packet session, also when the stream length is no multiple of the
+    group size, and after a seek that leaves the ring in the middle of a group"""
+    build_harness()
+    w, h = 320, 240
+    # (with a seek: an intra-only stream, so that what comes after the seek does not depend on what was dropped)
+    enc = R.OracleEncoder(w, h, 220) if seek else R.OracleEncoder(w, h, 220, 4, 2, 2)
+    pkts = [enc.encode(R.synth_frame(w, h, i // 2, seed=33, amp=5)) for i in range(23)]
+    env = {"MI_RTJ_IDX_GROUP": str(idx_group), "MI_RTJ_OUT_GROUP": str(out_group)}
+    opts = ["seek=7:12"] if seek else []  # after 7 pictures the demultiplexer repositions to packet 12
+    r, recs = run_pipe(tmp_path, pkts, w, h, *opts, depth=depth, extra_env=env)
+    assert r.returncode == 0, r.stderr
+    want = expected_stream(pkts, w, h, w, h, 0)
+    if seek:
+        want = want[:7] + want[12:]  # pictures 0..6, then the stream from packet 12 on
     assert len(recs) == len(want)
     for i, ((got, pts), (planes, wpts)) in enumerate(zip(recs, want)):
         assert np.array_equal(got, planes), i

@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(width=1920, height=1088, packets=64, repeat=32, depth=6, quality=255, amp=8, flavours=("", "_nocopy", "_pipe"),
+def run(width=1920, height=1088, packets=64, repeat=32, depth=12, quality=255, amp=8, flavours=("", "_nocopy", "_pipe"),
         two_streams=True, warm=None):
     warm = packets if warm is None else warm  # one lap untimed: the decoder allocates its buffers while the first packets come in
     P = importlib.import_module("gmerlin-avdecoder_amd")
@@ -59,6 +59,6 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--width", type=int, default=1920); ap.add_argument("--height", type=int, default=1088)
     ap.add_argument("--packets", type=int, default=64); ap.add_argument("--repeat", type=int, default=32)
-    ap.add_argument("--depth", type=int, default=6)
+    ap.add_argument("--depth", type=int, default=12)
     a = ap.parse_args()
     print(json.dumps(run(a.width, a.height, a.packets, a.repeat, a.depth)))
