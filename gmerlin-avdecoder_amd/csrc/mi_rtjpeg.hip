@@ -185,6 +185,7 @@ struct mi_rtj_pipe {
   // MI_RTJ_PIPE_STATS=1: where the submitting thread's time goes (seconds; printed to stderr when the session ends):
   // [0] copying packets into pinned staging, [1] runtime calls that queue work, [2] waiting for a picture's copy out
   bool stats = false;
+  int wait_mode = 0;
   double t_stage = 0, t_issue = 0, t_wait = 0, t_d2h_call = 0;  // t_d2h_call: inside hipMemcpyAsync of the copy out (part of t_issue)
   // The thread that submits is what bounds a session (about 50 us of runtime calls per packet next to the 30 us it
   // takes to copy a 1080p packet into pinned staging), so the two halves run on two threads: the caller copies, a
@@ -924,8 +925,11 @@ int mi_rtj_plan_spec_stats(mi_rtj_plan* p, int* proven, long long* walkers, long
   uint32_t nfix = 0;
   HIPCHK(c, hipMemcpyAsync(ok.data(), p->d_spec_ok, sizeof(uint32_t) * p->n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(&nfix, p->d_spec_nfix, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  uint32_t st[kSpecStWords] = {};
+  if (p->d_spec_state) HIPCHK(c, hipMemcpyAsync(st, p->d_spec_state, sizeof(st), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  *repaired = nfix;
+  // (while the speculation is paused no walker runs and nobody zeroes the repair count: it is the last unpaused launch's)
+  *repaired = st[kSpecStPause] ? 0 : nfix;
   for (uint32_t v : ok) *proven += v == 1u ? 1 : 0;
   return MI_RTJ_OK;
 }
@@ -1303,6 +1307,8 @@ mi_rtj_pipe* mi_rtj_pipe_create(mi_rtj_ctx* c, int depth, int max_w, int max_h) 
     q->exp_skip = sk ? atoi(sk) : 0;
     const char* ps = getenv("MI_RTJ_PIPE_STATS");
     q->stats = ps && atoi(ps) != 0;
+    const char* wm = getenv("MI_RTJ_WAIT");
+    q->wait_mode = wm && strcmp(wm, "query") == 0 ? 1 : 0;
   }
   {
     const char* og = getenv("MI_RTJ_OUT_GROUP");
@@ -1623,7 +1629,14 @@ int mi_rtj_pipe_next(mi_rtj_pipe* q, const uint8_t* planes[3], int strides[3], i
   }
   {
     const double tw0 = q->stats ? host_now() : 0.0;
-    HIPCHK(c, hipEventSynchronize(sl.out_ev ? sl.out_ev : sl.e_out));
+    hipEvent_t const ev = sl.out_ev ? sl.out_ev : sl.e_out;
+    if (q->wait_mode == 1) {  // MI_RTJ_WAIT=query (A/B): poll instead of blocking inside the runtime
+      hipError_t e;
+      while ((e = hipEventQuery(ev)) == hipErrorNotReady) std::this_thread::yield();
+      HIPCHK(c, e);
+    } else {
+      HIPCHK(c, hipEventSynchronize(ev));
+    }
     if (q->stats) q->t_wait += host_now() - tw0;
   }
   sl.out_state = 0;
