@@ -136,6 +136,11 @@ def run_streams4k(a, dev, shard, dist, red_dev, rank, world, barrier, sync_all, 
         lap()
     barrier()
     sync_all()
+    # the interpreter's cyclic collector is kept out of the timed region: a full collection in a process that has
+    # imported torch walks millions of objects and took 50 ms out of single laps of 11.6 (profiles/r03/streams4k_laps.txt)
+    import gc
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     lap_ms = []
     for _ in range(a.steps):
@@ -145,6 +150,7 @@ def run_streams4k(a, dev, shard, dist, red_dev, rank, world, barrier, sync_all, 
     sync_all()
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     # kernel times: a lap of its own with profiling on (it costs the submitting thread two event records per kernel)
     pipe.profile(True)
     lap()

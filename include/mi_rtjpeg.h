@@ -75,7 +75,10 @@ int mi_rtj_decode_nocopy(mi_rtj_ctx *ctx, const uint8_t *pkt, size_t len, const 
  * host memory the session owns (the nocopy source of lib/video.c:420-441; lib/video_v4l2_m2m.c:43-131 is the
  * in-tree precedent of a decoder with buffers in flight).  Copy in, kernels and copy out of up to `depth` packets
  * run side by side on three streams; unchanged (0xFF) blocks keep the previous picture of the stream as in the
- * reference (each packet's device picture starts as a copy of its predecessor's).
+ * reference (k_decode fetches them from the predecessor's device picture).
+ * With a coded size given, packets are indexed on the device and pictures copied out in groups (four of each from a
+ * depth of 12 on, else two; the depth is rounded up to whole groups): a packet is copied in at once, its kernels are
+ * queued when its group is complete or its picture is asked for, whichever comes first.
  *   depth            packets in flight plus the one picture on loan, 2..64
  *   coded_w, coded_h the stream's coded size (multiples of 16; 0 0 = take it from the packets): a packet whose header
  *                    says otherwise is refused before anything is allocated for it — the reference's frame has the
