@@ -1113,7 +1113,11 @@ int pipe_copy_out(mi_rtj_pipe* q, int last) {
   const size_t fsz = (size_t)z.w * z.h * 3 / 2;
   const size_t bytes = (size_t)(z.d_pic - a.d_pic) + fsz;  // one slot: fsz; a group: its members lie side by side
   hipStream_t so = q->s_out[(last / q->group) % q->n_out];
-  HIPCHK(c, hipStreamWaitEvent(so, z.e_dec, 0));  // the kernels of the earlier members ran before it, on the same stream
+  // "decoded" is recorded here, once per copy, not behind every packet's k_decode: the kernels of the group's members
+  // were queued before this point on the same stream (whatever else was queued behind them merely makes the copy wait
+  // a little longer: that only happens when the caller asks for a picture of an incomplete group)
+  HIPCHK(c, hipEventRecord(z.e_dec, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(so, z.e_dec, 0));
   if (q->exp_skip & 1) {
   } else if (q->out_kernel) {
     hipLaunchKernelGGL(k_copy16, dim3(q->out_kernel), dim3(256), 0, so, (const uint4*)a.d_pic, (uint4*)a.h_pic, bytes / 16);
@@ -1145,7 +1149,6 @@ int pipe_issue(mi_rtj_pipe* q, PipeSlot& sl) {
   p->prev_pic = sl.prev;
   const int rc = (q->exp_skip & 2) ? MI_RTJ_OK : plan_launch(p, sl.d_stage, sl.d_pic);
   if (rc != MI_RTJ_OK) return rc;
-  HIPCHK(c, hipEventRecord(sl.e_dec, c->stream));
   // copy out: queued now if this packet closes its group, else when the group's last packet is decoded or the caller
   // asks for one of its pictures, whichever comes first
   sl.out_state = 1;
@@ -1218,7 +1221,6 @@ int pipe_issue_group(mi_rtj_pipe* q, int first, int count) {
       const int rc = plan_launch(p, nullptr, sl.d_pic, kLaunchDecode, (uint32_t)j, 1);
       if (rc != MI_RTJ_OK) return rc;
     }
-    HIPCHK(c, hipEventRecord(sl.e_dec, c->stream));
     sl.staged = 0;
     sl.out_state = 1;
     q->nstaged--;
