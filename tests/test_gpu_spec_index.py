@@ -86,6 +86,41 @@ def test_speculation_is_taken_or_refused_as_expected(dev):
         dev.free(d_out)
 
 
+def test_packets_whose_length_is_a_whole_number_of_walker_chunks_are_proven(dev):
+    """the index's last entry is the END position, the start of a block that is not there: when the last block ends
+    exactly where the packet does and that is a chunk boundary, the end position is the first byte of a chunk past the
+    packet's last one, which needs a walker of its own (without it such packets — 1 in 2048 — were refused and went to
+    the exact kernels).  512x512 has 6144 blocks: a picture of nothing but unchanged (one-byte) blocks is three chunks."""
+    w, h, chunk = 512, 512, 2048
+    enc = R.OracleEncoder(w, h, 255, 100, 2, 2)
+    first = enc.encode(R.synth_frame(w, h, 0, amp=8))
+    same = enc.encode(R.synth_frame(w, h, 0, amp=8))  # the same picture again: every block unchanged
+    assert same.size - 12 == 6 * (w // 16) * (h // 16) == 3 * chunk and np.all(same[12:] == 0xFF)
+    pkts = [first, same]
+    up = (first.size - 12 + chunk - 1) // chunk * chunk  # zero bytes behind the last block are never parsed: the extra
+    for n in (up, up + 1, up + chunk - 1, up + chunk):   # walker then meets nothing but them
+        p = np.concatenate([first, np.zeros(12 + n - first.size, np.uint8)])
+        t = p.size
+        p[0:4] = [t & 255, (t >> 8) & 255, (t >> 16) & 255, (t >> 24) & 255]
+        pkts.append(p)
+    outs = T.batch_decode(dev, pkts, prefill=0x55)  # (checks the block index against the oracle's as well)
+    fsz = T.frame_bytes(w, h)
+    want = np.full(fsz, 0x55, np.uint8)
+    R.OracleDecoder().decode(first, want)
+    for i, got in enumerate(outs):
+        assert T.first_diff(got, np.full(fsz, 0x55, np.uint8) if i == 1 else want) is None, i
+    d_stream, po, pl, hdrs = dev.upload_packets(pkts, align=1)
+    d_out = dev.alloc(fsz * len(pkts))
+    plan = dev.plan(hdrs, po, pl, np.arange(len(pkts), dtype=np.uint64) * np.uint64(fsz))
+    plan.decode(d_stream, d_out)
+    dev.sync()
+    proven, walkers = plan.spec_stats()
+    assert proven == len(pkts), (proven, len(pkts))
+    plan.close()
+    dev.free(d_stream)
+    dev.free(d_out)
+
+
 def test_plans_that_keep_being_refused_pause_the_speculation(monkeypatch):
     """Device-side policy (k_spec_policy): a launch in which every packet was refused moves the plan to the
     walkers with the next longer lead (768 -> 1536 -> 6144 bytes); after two such launches with the longest, all
