@@ -449,12 +449,16 @@ def main():
                 e2e = importlib.import_module("tools.e2e_bench")
                 r2 = e2e.run(w, h, packets=min(n, 64), repeat=17)  # the first lap is not timed (the session's allocations)
                 two = r2.pop("two_streams_two_threads", {})
+                two_dflt = r2.pop("two_streams_two_threads_default_queues", {})
                 out["end_to_end"] = {"fps": max((v.get("fps", 0) for v in r2.values() if isinstance(v, dict)), default=0),
                                      "two_streams_fps": two.get("fps"),
+                                     "two_streams_default_hw_queues_fps": two_dflt.get("fps"),
                                      "pcie_cap_fps": r2["pcie_cap_fps"], "workload": r2.get("workload"), "by_flavour": {k: v for k, v in r2.items() if isinstance(v, dict)},
                                      "note": "fps: ONE stream, one host thread, through csrc/video_rtjpeg_mi355x.c, the best "
                                              "flavour (its default build: frame-owning with packets in flight, pictures leaving on "
-                                             "two copy streams); two_streams_fps: two instances on two threads, aggregate; "
+                                             "two copy streams); two_streams_fps: two instances on two threads of one process, aggregate, with "
+                                             "GPU_MAX_HW_QUEUES=8 (the runtime's default of four hardware queues makes two sessions' "
+                                             "eight streams share queues: two_streams_default_hw_queues_fps); "
                                              "the clock starts behind the first lap of the packet list (a session allocates its "
                                              "buffers while its first packets come in: the W untimed steps of this contract); "
                                              "pcie_cap_fps = what the host link gives ONE picture-sized pinned copy at a time "

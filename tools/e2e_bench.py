@@ -45,12 +45,19 @@ def run(width=1920, height=1088, packets=64, repeat=32, depth=12, quality=255, a
         except Exception:
             out[name] = {"error": (r.stderr or r.stdout)[-300:]}
         if fl == "_pipe" and two_streams:  # two decoder instances on two threads of one process: the aggregate
-            r = subprocess.run([exe, path, str(width), str(ih), "/dev/null", f"repeat={repeat}", "bench=1", "streams=2", f"warm={warm}"],
-                               capture_output=True, text=True, env=env, timeout=600)
-            try:
-                out["two_streams_two_threads"] = json.loads(r.stdout.strip().splitlines()[-1])
-            except Exception:
-                out["two_streams_two_threads"] = {"error": (r.stderr or r.stdout)[-300:]}
+            # A session has four HIP streams (kernels, copy in, two for copies out) and the runtime multiplexes all
+            # streams of a process onto GPU_MAX_HW_QUEUES hardware queues, four by default: two sessions then share
+            # queues, one's copy in waits behind the other's copy out, and the aggregate falls BELOW one session's rate
+            # (profiles/r03/e2e_two_streams.txt).  An application with several streams sets GPU_MAX_HW_QUEUES to four per
+            # session; both figures are reported.
+            for key, extra in (("two_streams_two_threads", {"GPU_MAX_HW_QUEUES": "8"}), ("two_streams_two_threads_default_queues", {})):
+                r = subprocess.run([exe, path, str(width), str(ih), "/dev/null", f"repeat={repeat}", "bench=1", "streams=2", f"warm={warm}"],
+                                   capture_output=True, text=True, env=dict(env, **extra), timeout=600)
+                try:
+                    out[key] = json.loads(r.stdout.strip().splitlines()[-1])
+                    out[key]["env"] = extra
+                except Exception:
+                    out[key] = {"error": (r.stderr or r.stdout)[-300:]}
     os.remove(path); os.rmdir(tmp)
     return out
 
