@@ -383,6 +383,9 @@ constexpr int kDecThreads = 64;
 #ifndef MIRTJ_DEC_ITERS
 #define MIRTJ_DEC_ITERS 11
 #endif
+#ifndef MIRTJ_CHROMA_POOL
+#define MIRTJ_CHROMA_POOL 0
+#endif
 constexpr int kCoefStride = MIRTJ_COEF_STRIDE;  // int16 per lane: 64 + 8 pad (144 B, conflict-free b128 reads)
 constexpr int kDecIters = MIRTJ_DEC_ITERS;      // macroblock groups a wave works through, one after the other (at most)
 constexpr int kSlotTabN = 64 + 16;              // slot table: 64 coefficient slots, then "block finished" entries
@@ -637,15 +640,60 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
   asm volatile("" ::"v"(cur.d[0]), "v"(cur.d[1]), "v"(cur.d[2]), "v"(cur.d[3]), "v"(cur.d[4]), "v"(cur.d[5]),
                "v"(cur.d[6]), "v"(cur.d[7]), "v"(cur.d[8]), "v"(pos_n));
 
+  // ---- pooled chroma rounds (kPool, -DMIRTJ_CHROMA_POOL=1; batch launches without `prev`) ----
+  // At high quality most chroma blocks are "DC, run of 63": 64 equal pixels.  A chroma round (64 blocks) then only
+  // CLASSIFIES its blocks: a lane keeps the pixel value and the class of its block in one register per pooled round
+  // (pl_info) and, when its block is a general one, puts the block's first eight stream bytes and where it came from into
+  // the 12 free bytes of the coefficient scratch of lane k, k = the block's rank among the general blocks pooled so far.
+  // When enough have come together (or the wave runs out of work) ONE transform round runs over them — a "virtual"
+  // iteration of this loop: bytes from the scratch instead of the look-ahead registers, no look-ahead loads, the
+  // pixels back into the scratch instead of memory — and then the home lanes of the pooled rounds store their rows,
+  // DC-only ones from the register, general ones from the scratch: whole row segments, as in a plain round.
+  constexpr bool kPool = kRot && !kPrev && (MIRTJ_CHROMA_POOL != 0);
+  constexpr uint32_t kPoolSlots = 3;       // pooled rounds at most (17 general blocks a round on the bench content)
+  constexpr uint32_t kPoolFlushFrom = 40;  // general blocks pooled from which the transform round runs next
+#ifdef MIRTJ_POOL_OFF
+  const bool pool_on = false;
+#else
+  const bool pool_on = kPool && bt8_c == 0u && ngroups < 65536u;
+#endif  // (tables with raw chroma bytes: every round is a plain one)
+  // per pooled round 16 bits per lane: pixel | class << 8 | rank << 10 (class 0 nothing to store, 1 DC only, 2 general),
+  // and the round's group (the same in every lane; vector registers: the kernel is short of scalar ones): two rounds to a register
+  uint32_t pl_info01 = 0u, pl_info2 = 0u, pl_grp01 = 0u, pl_grp2 = 0u;
+  uint32_t npool = 0, pool_g = 0;                   // wave-uniform: rounds pooled, general blocks pooled
+  bool virt = false, virt_last = false;             // wave-uniform: this iteration is the pooled blocks' transform round (the wave's last)
+  bool virt_fetch = false;                          // wave-uniform: ... run again with the blocks' bytes from the stream (one is longer than eight)
+
   MIRTJ_STAMP(0);  // prologue: descriptor, table, first offsets and bytes
-  for (uint32_t it = 0;; it++) {
-    const bool have_n = more_after(it);  // wave-uniform
+  for (uint32_t it = 0;;) {
+    if (kPool) {  // (wave-uniform all of them; said again so that the branches on them stay scalar branches)
+      virt = __builtin_amdgcn_readfirstlane((int)virt) != 0;
+      virt_last = __builtin_amdgcn_readfirstlane((int)virt_last) != 0;
+      virt_fetch = __builtin_amdgcn_readfirstlane((int)virt_fetch) != 0;
+      npool = (uint32_t)__builtin_amdgcn_readfirstlane((int)npool);
+      pool_g = (uint32_t)__builtin_amdgcn_readfirstlane((int)pool_g);
+    }
+    const bool have_n = kPool ? __builtin_amdgcn_readfirstlane((int)(!virt && more_after(it))) != 0 : more_after(it);  // wave-uniform
     const Src s0 = source(it);
-    const bool valid = s0.valid, valid_n = have_n && source(it + 1u).valid;
-    const uint32_t grp = s0.grp, dmb = s0.dmb, kblk = s0.kblk, mb = s0.mb;
-    pos_n = valid_n ? pos_n : 0u;
+    bool valid = s0.valid;
+    const bool valid_n = have_n && source(it + 1u).valid;
+    uint32_t grp = s0.grp, dmb = s0.dmb, kblk = s0.kblk, mb = s0.mb;
+    uint32_t vw0 = 0u, vw1 = 0u;
+    if (kPool && virt) {
+      const uint32_t code = *(const lds_u32_t*)(uintptr_t)(my_a + 132u);  // round << 8 | home lane
+      vw0 = *(const lds_u32_t*)(uintptr_t)(my_a + 136u);
+      vw1 = *(const lds_u32_t*)(uintptr_t)(my_a + 140u);
+      valid = (uint32_t)lane < pool_g;
+      const uint32_t j = code >> 8, hl = code & 63u;
+      grp = j == 0u ? (pl_grp01 & 0xFFFFu) : j == 1u ? (pl_grp01 >> 16) : pl_grp2;
+      dmb = hl & 31u;
+      kblk = 4u + (hl >> 5);
+      mb = grp * (uint32_t)kMbPerGroup + dmb;
+    } else {
+      pos_n = valid_n ? pos_n : 0u;
+    }
     if (rot) {  // the part in hand
-      chroma = s0.part == 2u;
+      chroma = (kPool && virt) || s0.part == 2u;
       bt8 = chroma ? bt8_c : bt8_y;
       tab_a = lds_address(s_tab) + (chroma ? 4u * (uint32_t)kSlotTabN : 0u);
       ca_end = (int)tab_a + 4 * 64;
@@ -653,12 +701,59 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
       stride = chroma ? f.w >> 1 : f.w;
     }
 
-    const uint32_t sh = (uint32_t)((uintptr_t)(data + pos0) & 3u);
+    uint32_t sh = (uint32_t)((uintptr_t)(data + pos0) & 3u);
     uint32_t d0 = cur.d[0], d1 = cur.d[1], d2 = cur.d[2], d3 = cur.d[3], d4 = cur.d[4];
+    uint32_t d5 = cur.d[5], d6 = cur.d[6], d7 = cur.d[7], d8 = cur.d[8];
+    uint32_t ppos = pos0;     // where the bytes in d0.. come from (blocks longer than 32 bytes fetch on from there)
+    bool pinside = inside;
+    if (kPool && virt) {
+      pinside = false;
+      if (!virt_fetch) {  // eight bytes from the pool, already aligned
+        sh = 0u;
+        d0 = vw0; d1 = vw1; d2 = d3 = d4 = d5 = d6 = d7 = d8 = 0u;
+      } else {            // second go (rare): one of the pooled blocks is longer — all of them from the stream, the plain way
+        ppos = off[valid ? 6u * mb + kblk : 0u];
+        ppos = valid ? ppos : 0u;
+        sh = (uint32_t)((uintptr_t)(data + ppos) & 3u);
+        const Bytes fb = fetch(ppos, false, 9);
+        d0 = fb.d[0]; d1 = fb.d[1]; d2 = fb.d[2]; d3 = fb.d[3]; d4 = fb.d[4];
+        d5 = fb.d[5]; d6 = fb.d[6]; d7 = fb.d[7]; d8 = fb.d[8];
+      }
+    }
     // unchanged block: previous pixels stay (lib/RTjpeg.c:2704)
-    const bool live_any = valid && (__builtin_amdgcn_alignbyte(d1, d0, sh) & 0xFFu) != 0xFFu;
+    const uint32_t first4 = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    const bool live_any = valid && (first4 & 0xFFu) != 0xFFu;
 
-    const bool live_blk = live_any;  // the lanes of this iteration's transform round
+    // a chroma round of a pooling wave: classify, keep, store nothing yet
+    bool pool_it = false;
+    if (kPool && pool_on && !virt && chroma) {
+      const uint32_t b1 = (first4 >> 8) & 0xFFu;
+      const uint32_t cls = !live_any ? 0u : b1 == 126u ? 1u : 2u;  // 126: a run of 63 slots behind the DC
+      const unsigned long long gm = __ballot(cls == 2u);
+      const uint32_t cnt = (uint32_t)__popcll(gm);
+      pool_it = __builtin_amdgcn_readfirstlane((int)(npool < kPoolSlots && pool_g + cnt <= 64u)) != 0;  // (else: a plain round)
+      if (pool_it) {
+        const uint32_t k = pool_g + (uint32_t)__popcll(gm & ((1ull << lane) - 1ull));
+        // the pixel of a DC-only block: what the transform makes of a lone DC (idct8_lo3(x0, 0, 0) is x0 in both passes)
+        const uint32_t q0 = *(const lds_u32_t*)(uintptr_t)tab_a >> 16;  // the DC's dequantiser (slot 0 of the chroma table)
+        const int dc = (int)(int16_t)((first4 & 0xFFu) * q0);
+        const uint32_t info = px(dc + 4) | (cls << 8) | ((k & 63u) << 10);
+        if (cls == 2u) {  // into lane k's scratch, bytes 132..143 (the coefficients end at 128, the dump is 128..129)
+          const uint32_t ea = lds_address(s_lds) + k * (uint32_t)(kCoefStride * 2);
+          *(lds_u32_t*)(uintptr_t)(ea + 132u) = (npool << 8) | (uint32_t)lane;
+          *(lds_u32_t*)(uintptr_t)(ea + 136u) = first4;
+          *(lds_u32_t*)(uintptr_t)(ea + 140u) = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        }
+        if (npool == 0u) { pl_info01 = info; pl_grp01 = grp; }
+        else if (npool == 1u) { pl_info01 |= info << 16; pl_grp01 |= grp << 16; }
+        else { pl_info2 = info; pl_grp2 = grp; }
+        npool++;
+        pool_g += cnt;
+      }
+    }
+    const bool live_blk = live_any && !pool_it;  // the lanes of this iteration's transform round
+    bool restart = false;
+    bool virt_direct_l = false;  // (set by the lanes of the one transform form that stores its rows itself in the pooled blocks' round)
 
     // (-DMIRTJ_EXP_NO_PARSE / -DMIRTJ_EXP_NO_TRANSFORM: census builds for the instruction budget of DESIGN.md section 8 —
     // wrong pictures, counted with rocprofv3 --pmc SQ_INSTS_VALU, never shipped)
@@ -679,6 +774,7 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
       uint32_t wd[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
                         __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
       int ca = (int)tab_a + 4 * ((int)bt8 + 1);  // DC and the raw bytes have their slots fixed
+      const bool short8 = kPool && virt && !virt_fetch;  // wave-uniform: only eight bytes are there
 
       // Eight bytes t0..t0+7 of the current 16.  A token is one coefficient or (64..127) a run of
       // token-63 zero slots (lib/RTjpeg.c:171-182); DC (unsigned; 0xFF was handled above) and raw byte t,
@@ -722,7 +818,7 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
       bool more = true;
       auto first_round = [&](auto b8c) {
         more = half_round(0, b8c, true);
-        if (more) more = half_round(8, b8c, true);
+        if (more && !short8) more = half_round(8, b8c, true);
       };
       switch (kForceGenericPaths ? 99u : bt8) {
         case 9: first_round(std::integral_constant<int, 9>{}); break;
@@ -731,19 +827,23 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
         case 0: first_round(std::integral_constant<int, 0>{}); break;
         default: first_round(std::integral_constant<int, -1>{}); break;
       }
+      if (short8) {  // (more: some pooled block is longer than eight bytes — found out below, outside this branch)
+        restart = more;
+        more = false;
+      }
       if (more) {
         // bytes 16..31 are in registers already
-        wd[0] = __builtin_amdgcn_alignbyte(cur.d[5], d4, sh);
-        wd[1] = __builtin_amdgcn_alignbyte(cur.d[6], cur.d[5], sh);
-        wd[2] = __builtin_amdgcn_alignbyte(cur.d[7], cur.d[6], sh);
-        wd[3] = __builtin_amdgcn_alignbyte(cur.d[8], cur.d[7], sh);
+        wd[0] = __builtin_amdgcn_alignbyte(d5, d4, sh);
+        wd[1] = __builtin_amdgcn_alignbyte(d6, d5, sh);
+        wd[2] = __builtin_amdgcn_alignbyte(d7, d6, sh);
+        wd[3] = __builtin_amdgcn_alignbyte(d8, d7, sh);
         more = half_round(0, std::integral_constant<int, -1>{}, false);
         if (more) more = half_round(8, std::integral_constant<int, -1>{}, false);
       }
-      uint32_t pnext = pos0 + 16u;
+      uint32_t pnext = ppos + 16u;
       while (more) {  // blocks longer than 32 bytes: fetched on demand
         pnext += 16u;
-        const Bytes nb = fetch(pnext, inside, 5);  // same alignment as pos0
+        const Bytes nb = fetch(pnext, pinside, 5);  // same alignment as the block's start
         wd[0] = __builtin_amdgcn_alignbyte(nb.d[1], nb.d[0], sh);
         wd[1] = __builtin_amdgcn_alignbyte(nb.d[2], nb.d[1], sh);
         wd[2] = __builtin_amdgcn_alignbyte(nb.d[3], nb.d[2], sh);
@@ -751,6 +851,10 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
         more = half_round(0, std::integral_constant<int, -1>{}, false);
         if (more) more = half_round(8, std::integral_constant<int, -1>{}, false);
       }
+    }
+    if (kPool && virt && !virt_fetch && __builtin_amdgcn_readfirstlane((int)__any(restart)) != 0) {  // wave-uniform
+      virt_fetch = true;
+      continue;  // the same round again, bytes from the stream
     }
 
     // ---- sessions with packets in flight give every packet a picture of its own: its unchanged (0xFF) blocks are
@@ -808,7 +912,7 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
 
     // ---- does any block of the wave reach outside the low 4x4?  (columns 4-7, rows 4-7) ----
     bool lo = false;
-    const bool try_lo = chroma ? try_lo_c : try_lo_y;
+    const bool try_lo = (chroma ? try_lo_c : try_lo_y) && !pool_it;  // (a pooling round transforms nothing)
     if (try_lo) {  // wave-uniform
       uint32_t hi = 0;
       if (live_blk) {
@@ -828,10 +932,19 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
     }
 
     MIRTJ_STAMP(2);  // look-ahead loads issued, low-4x4 test
-    if (live_any) {
+    if (live_blk) {
       const uint32_t off32 = block_offset(grp, dmb, kblk, mb);
       uint8_t* plane = outbuf + plane_off;  // wave-uniform; steps from row to row on the scalar side
+      // (the pooled blocks' round: the rows go back into the lane's scratch, whose coefficients the transform has
+      // read by then — but for the one form that reads the scratch twice, which holds its first four rows back)
+      uint32_t vrow = my_a;
       auto put_packed = [&](uint2 o) {  // one row of the block, already clamped and packed
+        if (kPool && virt && !virt_direct_l) {
+          *(lds_u32_t*)(uintptr_t)vrow = o.x;
+          *(lds_u32_t*)(uintptr_t)(vrow + 4u) = o.y;
+          vrow += 8u;
+          return;
+        }
         // nontemporal (global_store_dwordx2 ... nt): the picture is not read again by this kernel, and the
         // stores are what a short chroma round waits for (-3.5 % on the kernel, v21_nontemporal_stores_ab.txt)
         typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
@@ -992,6 +1105,10 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
 #endif
 #ifndef MIRTJ_EXP_PK_ONLY
         if (!packed) {
+          // (in the pooled blocks' round this form, which reads the scratch twice, stores its rows itself, 8-byte pieces
+          // at the blocks' own places — blocks outside the 16-bit budget: no encoder makes them — and the home lanes
+          // leave the general blocks alone)
+          if (kPool && virt) virt_direct_l = true;
           // ---- column pass: column c is one half of the 16-byte pieces c & ~1 (rows 0-3) and (c & ~1) + 1 (rows 4-7) ----
           // Two rounds, rows 0-3 and rows 4-7, each with a column pass of its own: this path is the rare one (a block
           // outside the 16-bit budget), and 32 + 32 registers of column results are what the kernel's register count —
@@ -1048,13 +1165,96 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
 #endif  // MIRTJ_EXP_PK_ONLY
       }
     }
+    if (kPool && virt) {
+      const bool virt_direct = __any(virt_direct_l);  // wave-uniform (the form is chosen per wave)
+      // ---- the pooled rounds' rows leave now: DC-only blocks from the register, general ones from the scratch of the
+      //      lane that transformed them (one wave, LDS operations in order: the fences keep the compiler from reordering) ----
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+      for (uint32_t j = 0; j < npool; j++) {  // (wave-uniform; rolled: the rows of one round at a time in registers)
+        const uint32_t info = j == 0u ? pl_info01 & 0xFFFFu : j == 1u ? pl_info01 >> 16 : pl_info2;
+        const uint32_t cls = (info >> 8) & 3u;
+        if (cls != 0u && !(virt_direct && cls == 2u)) {
+          const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)(j == 0u ? pl_grp01 & 0xFFFFu : j == 1u ? pl_grp01 >> 16 : pl_grp2));
+          const uint32_t hdmb = (uint32_t)(lane & 31), hk = 4u + (uint32_t)(lane >> 5);
+          uint32_t o = block_offset(g, hdmb, hk, g * (uint32_t)kMbPerGroup + hdmb);
+          uint8_t* const plane = outbuf + plane_off;
+          const uint32_t fill = (info & 0xFFu) * 0x01010101u;
+          const uint32_t ra = lds_address(s_lds) + ((info >> 10) & 63u) * (uint32_t)(kCoefStride * 2);
+#pragma unroll 2
+          for (int r = 0; r < 8; r++) {
+            typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+            u32x2_t ov;
+            ov.x = fill;
+            ov.y = fill;
+            if (cls == 2u) {
+              ov.x = *(const lds_u32_t*)(uintptr_t)(ra + 8u * (uint32_t)r);
+              ov.y = *(const lds_u32_t*)(uintptr_t)(ra + 8u * (uint32_t)r + 4u);
+            }
+            __builtin_nontemporal_store(ov, (u32x2_t*)(plane + o));
+            o += stride;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the scratch is written again by the next round's parse
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      npool = 0u;
+      pool_g = 0u;
+      virt = false;
+      virt_fetch = false;
+      if (virt_last) break;
+      continue;  // on with iteration `it`, whose bytes have been waiting in `cur`
+    }
     MIRTJ_STAMP(3);  // coordinates, transform, row stores
-    if (!have_n) break;
+    if (!have_n) {
+      if (kPool && npool != 0u) {  // the wave's last round is done: the pool's transform round, then out
+        virt = true;
+        virt_last = true;
+        continue;
+      }
+      break;
+    }
+    // Every transform variant ends with kRowStores row stores, so behind the join "all but the kRowStores youngest
+    // operations" is exactly "everything requested before the transform" — unless no lane had a live block: such a wave
+    // stored nothing and waits for all there is.  (kRowStores sits next to the stores it counts: put_packed above.)
+    const uint32_t younger = __ballot(live_blk) != 0ull ? (uint32_t)kRowStores : 0u;  // (a pooling round stores nothing)
+    if (kPool) {
+      // The wait and the copies out of the registers being filled in ONE block: with this loop's control flow the
+      // compiler, given the registers as in/out operands of a wait block of its own (the form below), ties them to other
+      // registers and copies them IN FRONT of the wait (tools/check_async_loads.py found it).  Plain inputs need no
+      // copy, and what reads them stands behind the wait in the same text.
+      uint32_t c0, c1, c2, c3, c4, c5, c6, c7, c8, pn;
+      asm volatile(
+          "s_cmp_eq_u32 %20, 8\n\t"
+          "s_cbranch_scc1 .Lmirtj_w8_%=\n\t"
+          "s_waitcnt vmcnt(0)\n\t"
+          "s_branch .Lmirtj_arrived_%=\n"
+          ".Lmirtj_w8_%=:\n\t"
+          "s_waitcnt vmcnt(8)\n"
+          ".Lmirtj_arrived_%=:\n\t"
+          "v_mov_b32 %0, %10\n\tv_mov_b32 %1, %11\n\tv_mov_b32 %2, %12\n\tv_mov_b32 %3, %13\n\tv_mov_b32 %4, %14\n\t"
+          "v_mov_b32 %5, %15\n\tv_mov_b32 %6, %16\n\tv_mov_b32 %7, %17\n\tv_mov_b32 %8, %18\n\tv_mov_b32 %9, %19"
+          : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&v"(c4), "=&v"(c5), "=&v"(c6), "=&v"(c7), "=&v"(c8), "=&v"(pn)
+          : "v"(nb0.x), "v"(nb0.y), "v"(nb0.z), "v"(nb0.w), "v"(nb1.x), "v"(nb1.y), "v"(nb1.z), "v"(nb1.w), "v"(nb2),
+            "v"(pos_nn), "s"(younger)
+          : "scc", "memory");
+      MIRTJ_STAMP(4);
+      pos0 = pos_n;
+      pos_n = pn;
+      if (inside_n) {
+        cur.d[0] = c0; cur.d[1] = c1; cur.d[2] = c2; cur.d[3] = c3; cur.d[4] = c4;
+        cur.d[5] = c5; cur.d[6] = c6; cur.d[7] = c7; cur.d[8] = c8;
+      } else {
+        cur = fetch(pos0, false, 9);
+      }
+    } else {
     // Every transform variant ends with kRowStores row stores, so behind the join "all but the kRowStores youngest
     // operations" is exactly "everything requested before the transform" — unless no lane had a live block: such a wave
     // stored nothing and waits for all there is.  (kRowStores sits next to the stores it counts: put_packed above.)
     {
-      const uint32_t younger = __ballot(live_any) != 0ull ? (uint32_t)kRowStores : 0u;
       asm volatile(
           "s_cmp_eq_u32 %4, 8\n\t"
           "s_cbranch_scc1 .Lmirtj_w8_%=\n\t"
@@ -1079,7 +1279,12 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
     } else {
       cur = fetch(pos0, false, 9);
     }
+    }
     inside = inside_n;
+    it++;
+    // the pool's transform round runs next when the pooled rounds' registers are used up or another round's general
+    // blocks might not fit in (a round that does not fit is a plain round, see above)
+    if (kPool && (npool == kPoolSlots || pool_g >= kPoolFlushFrom)) virt = true;
   }
 #ifdef MIRTJ_STAMPS
   if (lane == 0) {
