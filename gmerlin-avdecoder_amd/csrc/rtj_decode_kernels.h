@@ -640,60 +640,263 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
   asm volatile("" ::"v"(cur.d[0]), "v"(cur.d[1]), "v"(cur.d[2]), "v"(cur.d[3]), "v"(cur.d[4]), "v"(cur.d[5]),
                "v"(cur.d[6]), "v"(cur.d[7]), "v"(cur.d[8]), "v"(pos_n));
 
-  // ---- pooled chroma rounds (kPool, -DMIRTJ_CHROMA_POOL=1; batch launches without `prev`) ----
+  // ---- pooled chroma rounds (kPool, -DMIRTJ_CHROMA_POOL=1; batch launches without `prev`; second form of the prototype) ----
   // At high quality most chroma blocks are "DC, run of 63": 64 equal pixels.  A chroma round (64 blocks) then only
-  // CLASSIFIES its blocks: a lane keeps the pixel value and the class of its block in one register per pooled round
-  // (pl_info) and, when its block is a general one, puts the block's first eight stream bytes and where it came from into
-  // the 12 free bytes of the coefficient scratch of lane k, k = the block's rank among the general blocks pooled so far.
-  // When enough have come together (or the wave runs out of work) ONE transform round runs over them — a "virtual"
-  // iteration of this loop: bytes from the scratch instead of the look-ahead registers, no look-ahead loads, the
-  // pixels back into the scratch instead of memory — and then the home lanes of the pooled rounds store their rows,
-  // DC-only ones from the register, general ones from the scratch: whole row segments, as in a plain round.
+  // CLASSIFIES its blocks: a lane keeps the pixel value and the class of its block (16 bits per pooled round) and, when
+  // its block is a general one, puts the block's first eight stream bytes into the 12 free bytes of the coefficient
+  // scratch of lane k, k = the block's rank among the general blocks pooled so far.  When enough have come together (or
+  // the wave runs out of work) ONE transform round runs over them — a block of its own at the top of the loop, with the
+  // short forms of the transform only — and then the home lanes of the pooled rounds store their rows, DC-only ones from
+  // the register, general ones from the scratch: whole row segments, as in a plain round.  Pooled blocks the short forms
+  // do not cover (longer than eight bytes, coefficients outside the low 4x4: no encoder makes such chroma at these
+  // qualities) send the wave BACK to the first pooled round, to run everything from there again without pooling.
   constexpr bool kPool = kRot && !kPrev && (MIRTJ_CHROMA_POOL != 0);
   constexpr uint32_t kPoolSlots = 3;       // pooled rounds at most (17 general blocks a round on the bench content)
   constexpr uint32_t kPoolFlushFrom = 40;  // general blocks pooled from which the transform round runs next
 #ifdef MIRTJ_POOL_OFF
   const bool pool_on = false;
 #else
-  const bool pool_on = kPool && bt8_c == 0u && ngroups < 65536u;
-#endif  // (tables with raw chroma bytes: every round is a plain one)
-  // per pooled round 16 bits per lane: pixel | class << 8 | rank << 10 (class 0 nothing to store, 1 DC only, 2 general),
-  // and the round's group (the same in every lane; vector registers: the kernel is short of scalar ones): two rounds to a register
-  uint32_t pl_info01 = 0u, pl_info2 = 0u, pl_grp01 = 0u, pl_grp2 = 0u;
-  uint32_t npool = 0, pool_g = 0;                   // wave-uniform: rounds pooled, general blocks pooled
-  bool virt = false, virt_last = false;             // wave-uniform: this iteration is the pooled blocks' transform round (the wave's last)
-  bool virt_fetch = false;                          // wave-uniform: ... run again with the blocks' bytes from the stream (one is longer than eight)
+  const bool pool_on = kPool && bt8_c == 0u;  // (tables with raw chroma bytes: every round is a plain one)
+#endif
+  // What a lane keeps per pooled round — pixel | class << 8 | rank << 10 (class 0 nothing to store, 1 DC only, 2 general) —
+  // lives in bytes 130..135 of its coefficient scratch (three rounds of 16 bits), the rounds' groups and the iteration
+  // of the first pooled round in spare entries of the luma slot table (entries past 64 are never read by the parse):
+  // the kernel has neither vector nor scalar registers to spare.
+  const uint32_t pool_tab = lds_address(s_tab) + 4u * 70u;  // [0..2] groups, [3] first pooled iteration, [4] no pooling before this iteration
+  uint32_t npool = 0, pool_g = 0;        // wave-uniform: rounds pooled, general blocks pooled
+  if (kPool && lane == 0) *(lds_u32_t*)(uintptr_t)(pool_tab + 16u) = 0u;
+  bool virt = false, virt_last = false;  // wave-uniform: the pooled blocks' transform round runs next (and is the wave's last act)
+  const IdctK K{362, 473, -669, 277, 128, 235};
+  const IdctPK KP = idct_pk_constants();
+  auto half16 = [](uint32_t w, int odd) -> int { return odd ? (int)w >> 16 : (int)(int16_t)(w & 0xFFFFu); };
+  // the transform's forms for blocks inside the low 4x4 (three-input, packed or not; four-input), rows handed to `putp`
+  auto lo_forms = [&](auto&& putp) {
+    auto putr = [&](const int (&y)[8]) {
+      uint2 o;
+      o.x = lshl_or(lshl_or(px(y[3]), 8, px(y[2])), 16, lshl_or(px(y[1]), 8, px(y[0])));
+      o.y = lshl_or(lshl_or(px(y[7]), 8, px(y[6])), 16, lshl_or(px(y[5]), 8, px(y[4])));
+      putp(o);
+    };
+    (void)putr;
+        // rows 0-3 of the column pairs (0, 1) and (2, 3)
+        const uint4 qa = my[0], qb = my[2];
+        // anything in row 3 or column 3?  (the lanes of this branch: those with a live block)
+        const uint32_t t3 = qa.w | qb.w | ((qb.x | qb.y | qb.z) & 0xFFFF0000u);
+#ifdef MIRTJ_EXP_FIXED_PATHS
+        if (true || !__any(t3 != 0u)) {
+#else
+        if (!__any(t3 != 0u)) {
+#endif
+          // ---- three-input transform: columns 0-2 in, rows of three in ----
+#if MIRTJ_PK_IDCT
+          const bool fits = __all(pk_range_lo3(qa, qb, KP));
+          MIRTJ_STAMP(5);  // coordinates, scratch reads, 16-bit range test
+#ifdef MIRTJ_EXP_PK_ONLY
+          if (true) {
+#else
+          if (fits) {
+#endif
+            // two columns, then two rows, to a register (rtj_idct_pk.h)
+            uint32_t ya[8], yb[8];
+            idct8_pk_lo3_col<true>(qa.x, qa.y, qa.z, ya, KP);   // columns 0, 1
+            idct8_pk_lo3_col<false>(qb.x, qb.y, qb.z, yb, KP);  // columns 2, (3: zero)
+#pragma unroll
+            for (int r = 0; r < 8; r += 2) {
+              uint2 o0, o1;
+              idct8_pk_lo3_row_px(ya[r], ya[r + 1], yb[r], yb[r + 1], o0, o1, KP);
+              putp(o0);
+              putp(o1);
+            }
+          } else
+#endif
+#ifndef MIRTJ_EXP_PK_ONLY
+          {
+            int ws[8][3];
+#if MIRTJ_ASM_IDCT
+            {
+              int y[8];
+              idct8_lo3_col<true, false>(qa.x, qa.y, qa.z, y, K);
+#pragma unroll
+              for (int r = 0; r < 8; r++) ws[r][0] = y[r];
+              idct8_lo3_col<false, true>(qa.x, qa.y, qa.z, y, K);
+#pragma unroll
+              for (int r = 0; r < 8; r++) ws[r][1] = y[r];
+              idct8_lo3_col<false, false>(qb.x, qb.y, qb.z, y, K);
+#pragma unroll
+              for (int r = 0; r < 8; r++) ws[r][2] = y[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) putp(idct8_lo3_row_px(ws[r][0], ws[r][1], ws[r][2], K));
+#else
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+              const uint4& q = c < 2 ? qa : qb;
+              int x0 = half16(q.x, c & 1);
+              const int x1 = half16(q.y, c & 1), x2 = half16(q.z, c & 1);
+              if (c == 0) x0 += 4;  // DESCALE's rounding term, carried through both linear DC paths
+              int y[8];
+              idct8_lo3(x0, x1, x2, y);
+#pragma unroll
+              for (int r = 0; r < 8; r++) ws[r][c] = y[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+              int y[8];
+              idct8_lo3(ws[r][0], ws[r][1], ws[r][2], y);
+              putr(y);
+            }
+#endif
+          }
+#else
+          {}
+#endif  // MIRTJ_EXP_PK_ONLY
+        } else {
+          // ---- four-input transform: columns 0-3 in, rows of four in ----
+#ifndef MIRTJ_EXP_PK_ONLY
+          int ws[8][4];
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            const uint4& q = c < 2 ? qa : qb;
+            int x0 = half16(q.x, c & 1);
+            const int x1 = half16(q.y, c & 1), x2 = half16(q.z, c & 1), x3 = half16(q.w, c & 1);
+            if (c == 0) x0 += 4;  // DESCALE's rounding term, carried through both linear DC paths
+            int y[8];
+            idct8_lo(x0, x1, x2, x3, y);
+#pragma unroll
+            for (int r = 0; r < 8; r++) ws[r][c] = y[r];
+          }
+#pragma unroll
+          for (int r = 0; r < 8; r++) {
+            int y[8];
+            idct8_lo(ws[r][0], ws[r][1], ws[r][2], ws[r][3], y);
+            putr(y);
+          }
+#endif
+        }
+  };
 
   MIRTJ_STAMP(0);  // prologue: descriptor, table, first offsets and bytes
   for (uint32_t it = 0;;) {
-    if (kPool) {  // (wave-uniform all of them; said again so that the branches on them stay scalar branches)
-      virt = __builtin_amdgcn_readfirstlane((int)virt) != 0;
-      virt_last = __builtin_amdgcn_readfirstlane((int)virt_last) != 0;
-      virt_fetch = __builtin_amdgcn_readfirstlane((int)virt_fetch) != 0;
-      npool = (uint32_t)__builtin_amdgcn_readfirstlane((int)npool);
-      pool_g = (uint32_t)__builtin_amdgcn_readfirstlane((int)pool_g);
-    }
-    const bool have_n = kPool ? __builtin_amdgcn_readfirstlane((int)(!virt && more_after(it))) != 0 : more_after(it);  // wave-uniform
-    const Src s0 = source(it);
-    bool valid = s0.valid;
-    const bool valid_n = have_n && source(it + 1u).valid;
-    uint32_t grp = s0.grp, dmb = s0.dmb, kblk = s0.kblk, mb = s0.mb;
-    uint32_t vw0 = 0u, vw1 = 0u;
+    if (kPool) virt = __builtin_amdgcn_readfirstlane((int)virt) != 0;
     if (kPool && virt) {
-      const uint32_t code = *(const lds_u32_t*)(uintptr_t)(my_a + 132u);  // round << 8 | home lane
-      vw0 = *(const lds_u32_t*)(uintptr_t)(my_a + 136u);
-      vw1 = *(const lds_u32_t*)(uintptr_t)(my_a + 140u);
-      valid = (uint32_t)lane < pool_g;
-      const uint32_t j = code >> 8, hl = code & 63u;
-      grp = j == 0u ? (pl_grp01 & 0xFFFFu) : j == 1u ? (pl_grp01 >> 16) : pl_grp2;
-      dmb = hl & 31u;
-      kblk = 4u + (hl >> 5);
-      mb = grp * (uint32_t)kMbPerGroup + dmb;
-    } else {
-      pos_n = valid_n ? pos_n : 0u;
+      // ---- the pooled blocks' transform round ----
+      const bool vlive = (uint32_t)lane < pool_g;
+      const uint32_t tab_c = lds_address(s_tab) + 4u * (uint32_t)kSlotTabN;
+      const int cend = (int)tab_c + 4 * 64;
+      bool unfinished = false;
+      uint32_t hi = 0u;
+      if (vlive) {
+        const uint32_t w0 = *(const lds_u32_t*)(uintptr_t)(my_a + 136u), w1 = *(const lds_u32_t*)(uintptr_t)(my_a + 140u);
+        {
+          uint4* z = (uint4*)my;
+#pragma unroll
+          for (int i = 0; i < 8; i++) z[i] = make_uint4(0, 0, 0, 0);
+        }
+        const uint32_t e0 = *(const lds_u32_t*)(uintptr_t)tab_c;
+        *(lds_i16_t*)(uintptr_t)(my_a + (uint32_t)slot_byte(0)) = (int16_t)mul_byte_hi16(w0, e0, 0, false);
+        int ca = (int)tab_c + 4;
+        int svb[7];
+        uint32_t e[7];
+#pragma unroll
+        for (int k = 1; k < 8; k++) {
+          const uint32_t w = k < 4 ? w0 : w1;
+          svb[k - 1] = sbyte_minus(w, k & 3, k63);
+          e[k - 1] = *(const lds_u32_t*)(uintptr_t)(uint32_t)ca;
+          ca = med3_i32(ca + 4, (svb[k - 1] << 2) + ca, cend);
+        }
+#pragma unroll
+        for (int k = 1; k < 8; k++) {
+          const uint32_t w = k < 4 ? w0 : w1;
+          int prod = mul_byte_hi16(w, e[k - 1], k & 3, true);
+          prod = svb[k - 1] > 0 ? 0 : prod;
+          *(lds_i16_t*)(uintptr_t)(my_a + (e[k - 1] & 0xFFFFu)) = (int16_t)prod;
+        }
+        unfinished = ca < cend;  // the block goes on behind its eighth byte
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          if (i == 0 || i == 2) continue;  // rows 0-3 of columns 0-3
+          const uint4 q = my[i];
+          hi |= q.x | q.y | q.z | q.w;
+        }
+      }
+      const bool bail = __builtin_amdgcn_readfirstlane((int)__any(unfinished || hi != 0u)) != 0;  // wave-uniform
+      if (!bail) {
+        chroma = 1;
+        plane_off = f.out_off + ysz;
+        stride = f.w >> 1;
+        if (vlive) {
+          uint32_t vrow = my_a;  // the rows go back into the lane's scratch (its coefficients are in registers by then)
+          auto put_lds = [&](uint2 o) {
+            *(lds_u32_t*)(uintptr_t)vrow = o.x;
+            *(lds_u32_t*)(uintptr_t)(vrow + 4u) = o.y;
+            vrow += 8u;
+          };
+          lo_forms(put_lds);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (one wave, LDS operations in order: for the compiler)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // the pooled rounds' rows leave now
+#pragma unroll 1
+        for (uint32_t j = 0; j < npool; j++) {
+          const uint32_t info = *(const __attribute__((address_space(3))) uint16_t*)(uintptr_t)(my_a + 130u + 2u * j);
+          const uint32_t cls = (info >> 8) & 3u;
+          if (cls != 0u) {
+            const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const lds_u32_t*)(uintptr_t)(pool_tab + 4u * j));
+            const uint32_t hdmb = (uint32_t)(lane & 31), hk = 4u + (uint32_t)(lane >> 5);
+            const uint32_t o = block_offset(g, hdmb, hk, g * (uint32_t)kMbPerGroup + hdmb);
+            uint8_t* plane = outbuf + plane_off;  // wave-uniform; steps from row to row on the scalar side
+            const uint32_t fill = (info & 0xFFu) * 0x01010101u;
+            uint32_t ra = lds_address(s_lds) + ((info >> 10) & 63u) * (uint32_t)(kCoefStride * 2);
+#pragma unroll 1
+            for (int r = 0; r < 8; r++) {
+              typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+              u32x2_t ov;
+              ov.x = fill;
+              ov.y = fill;
+              if (cls == 2u) {
+                ov.x = *(const lds_u32_t*)(uintptr_t)ra;
+                ov.y = *(const lds_u32_t*)(uintptr_t)(ra + 4u);
+              }
+              __builtin_nontemporal_store(ov, (u32x2_t*)(plane + o));
+              plane += stride;
+              ra += 8u;
+            }
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the scratch is written again by the next round's parse
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        npool = 0u;
+        pool_g = 0u;
+        virt = false;
+        if (virt_last) break;
+        continue;  // on with iteration `it`, whose bytes have been waiting in `cur`
+      }
+      // ---- the way back: from the first pooled round on, everything again, plain ----
+      if (lane == 0) *(lds_u32_t*)(uintptr_t)(pool_tab + 16u) = virt_last ? it + 1u : it;
+      it = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const lds_u32_t*)(uintptr_t)(pool_tab + 12u));
+      npool = 0u;
+      pool_g = 0u;
+      virt = false;
+      virt_last = false;
+      {
+        const Src r0 = source(it), r1 = source(it + 1u);
+        pos0 = off[r0.valid ? 6u * r0.mb + r0.kblk : 0u];
+        pos_n = off[r1.valid ? 6u * r1.mb + r1.kblk : 0u];
+        pos0 = r0.valid ? pos0 : 0u;
+        inside = !kForceGenericPaths && __all(pos0 + kFetchSpan <= f.data_len);
+        cur = fetch(pos0, inside, 9);
+      }
+      continue;
     }
+    const bool have_n = more_after(it);  // wave-uniform
+    const Src s0 = source(it);
+    const bool valid = s0.valid, valid_n = have_n && source(it + 1u).valid;
+    const uint32_t grp = s0.grp, dmb = s0.dmb, kblk = s0.kblk, mb = s0.mb;
+    pos_n = valid_n ? pos_n : 0u;
     if (rot) {  // the part in hand
-      chroma = (kPool && virt) || s0.part == 2u;
+      chroma = s0.part == 2u;
       bt8 = chroma ? bt8_c : bt8_y;
       tab_a = lds_address(s_tab) + (chroma ? 4u * (uint32_t)kSlotTabN : 0u);
       ca_end = (int)tab_a + 4 * 64;
@@ -701,32 +904,15 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
       stride = chroma ? f.w >> 1 : f.w;
     }
 
-    uint32_t sh = (uint32_t)((uintptr_t)(data + pos0) & 3u);
+    const uint32_t sh = (uint32_t)((uintptr_t)(data + pos0) & 3u);
     uint32_t d0 = cur.d[0], d1 = cur.d[1], d2 = cur.d[2], d3 = cur.d[3], d4 = cur.d[4];
-    uint32_t d5 = cur.d[5], d6 = cur.d[6], d7 = cur.d[7], d8 = cur.d[8];
-    uint32_t ppos = pos0;     // where the bytes in d0.. come from (blocks longer than 32 bytes fetch on from there)
-    bool pinside = inside;
-    if (kPool && virt) {
-      pinside = false;
-      if (!virt_fetch) {  // eight bytes from the pool, already aligned
-        sh = 0u;
-        d0 = vw0; d1 = vw1; d2 = d3 = d4 = d5 = d6 = d7 = d8 = 0u;
-      } else {            // second go (rare): one of the pooled blocks is longer — all of them from the stream, the plain way
-        ppos = off[valid ? 6u * mb + kblk : 0u];
-        ppos = valid ? ppos : 0u;
-        sh = (uint32_t)((uintptr_t)(data + ppos) & 3u);
-        const Bytes fb = fetch(ppos, false, 9);
-        d0 = fb.d[0]; d1 = fb.d[1]; d2 = fb.d[2]; d3 = fb.d[3]; d4 = fb.d[4];
-        d5 = fb.d[5]; d6 = fb.d[6]; d7 = fb.d[7]; d8 = fb.d[8];
-      }
-    }
     // unchanged block: previous pixels stay (lib/RTjpeg.c:2704)
     const uint32_t first4 = __builtin_amdgcn_alignbyte(d1, d0, sh);
     const bool live_any = valid && (first4 & 0xFFu) != 0xFFu;
 
     // a chroma round of a pooling wave: classify, keep, store nothing yet
     bool pool_it = false;
-    if (kPool && pool_on && !virt && chroma) {
+    if (kPool && pool_on && chroma && it >= *(const lds_u32_t*)(uintptr_t)(pool_tab + 16u)) {
       const uint32_t b1 = (first4 >> 8) & 0xFFu;
       const uint32_t cls = !live_any ? 0u : b1 == 126u ? 1u : 2u;  // 126: a run of 63 slots behind the DC
       const unsigned long long gm = __ballot(cls == 2u);
@@ -738,22 +924,21 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
         const uint32_t q0 = *(const lds_u32_t*)(uintptr_t)tab_a >> 16;  // the DC's dequantiser (slot 0 of the chroma table)
         const int dc = (int)(int16_t)((first4 & 0xFFu) * q0);
         const uint32_t info = px(dc + 4) | (cls << 8) | ((k & 63u) << 10);
-        if (cls == 2u) {  // into lane k's scratch, bytes 132..143 (the coefficients end at 128, the dump is 128..129)
+        if (cls == 2u) {  // into lane k's scratch, bytes 136..143 (the coefficients end at 128, the dump is 128..129)
           const uint32_t ea = lds_address(s_lds) + k * (uint32_t)(kCoefStride * 2);
-          *(lds_u32_t*)(uintptr_t)(ea + 132u) = (npool << 8) | (uint32_t)lane;
           *(lds_u32_t*)(uintptr_t)(ea + 136u) = first4;
           *(lds_u32_t*)(uintptr_t)(ea + 140u) = __builtin_amdgcn_alignbyte(d2, d1, sh);
         }
-        if (npool == 0u) { pl_info01 = info; pl_grp01 = grp; }
-        else if (npool == 1u) { pl_info01 |= info << 16; pl_grp01 |= grp << 16; }
-        else { pl_info2 = info; pl_grp2 = grp; }
+        *(__attribute__((address_space(3))) uint16_t*)(uintptr_t)(my_a + 130u + 2u * npool) = (uint16_t)info;
+        if (lane == 0) {
+          *(lds_u32_t*)(uintptr_t)(pool_tab + 4u * npool) = grp;
+          if (npool == 0u) *(lds_u32_t*)(uintptr_t)(pool_tab + 12u) = it;
+        }
         npool++;
         pool_g += cnt;
       }
     }
     const bool live_blk = live_any && !pool_it;  // the lanes of this iteration's transform round
-    bool restart = false;
-    bool virt_direct_l = false;  // (set by the lanes of the one transform form that stores its rows itself in the pooled blocks' round)
 
     // (-DMIRTJ_EXP_NO_PARSE / -DMIRTJ_EXP_NO_TRANSFORM: census builds for the instruction budget of DESIGN.md section 8 —
     // wrong pictures, counted with rocprofv3 --pmc SQ_INSTS_VALU, never shipped)
@@ -774,7 +959,6 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
       uint32_t wd[4] = {__builtin_amdgcn_alignbyte(d1, d0, sh), __builtin_amdgcn_alignbyte(d2, d1, sh),
                         __builtin_amdgcn_alignbyte(d3, d2, sh), __builtin_amdgcn_alignbyte(d4, d3, sh)};
       int ca = (int)tab_a + 4 * ((int)bt8 + 1);  // DC and the raw bytes have their slots fixed
-      const bool short8 = kPool && virt && !virt_fetch;  // wave-uniform: only eight bytes are there
 
       // Eight bytes t0..t0+7 of the current 16.  A token is one coefficient or (64..127) a run of
       // token-63 zero slots (lib/RTjpeg.c:171-182); DC (unsigned; 0xFF was handled above) and raw byte t,
@@ -818,7 +1002,7 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
       bool more = true;
       auto first_round = [&](auto b8c) {
         more = half_round(0, b8c, true);
-        if (more && !short8) more = half_round(8, b8c, true);
+        if (more) more = half_round(8, b8c, true);
       };
       switch (kForceGenericPaths ? 99u : bt8) {
         case 9: first_round(std::integral_constant<int, 9>{}); break;
@@ -827,23 +1011,19 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
         case 0: first_round(std::integral_constant<int, 0>{}); break;
         default: first_round(std::integral_constant<int, -1>{}); break;
       }
-      if (short8) {  // (more: some pooled block is longer than eight bytes — found out below, outside this branch)
-        restart = more;
-        more = false;
-      }
       if (more) {
         // bytes 16..31 are in registers already
-        wd[0] = __builtin_amdgcn_alignbyte(d5, d4, sh);
-        wd[1] = __builtin_amdgcn_alignbyte(d6, d5, sh);
-        wd[2] = __builtin_amdgcn_alignbyte(d7, d6, sh);
-        wd[3] = __builtin_amdgcn_alignbyte(d8, d7, sh);
+        wd[0] = __builtin_amdgcn_alignbyte(cur.d[5], d4, sh);
+        wd[1] = __builtin_amdgcn_alignbyte(cur.d[6], cur.d[5], sh);
+        wd[2] = __builtin_amdgcn_alignbyte(cur.d[7], cur.d[6], sh);
+        wd[3] = __builtin_amdgcn_alignbyte(cur.d[8], cur.d[7], sh);
         more = half_round(0, std::integral_constant<int, -1>{}, false);
         if (more) more = half_round(8, std::integral_constant<int, -1>{}, false);
       }
-      uint32_t pnext = ppos + 16u;
+      uint32_t pnext = pos0 + 16u;
       while (more) {  // blocks longer than 32 bytes: fetched on demand
         pnext += 16u;
-        const Bytes nb = fetch(pnext, pinside, 5);  // same alignment as the block's start
+        const Bytes nb = fetch(pnext, inside, 5);  // same alignment as pos0
         wd[0] = __builtin_amdgcn_alignbyte(nb.d[1], nb.d[0], sh);
         wd[1] = __builtin_amdgcn_alignbyte(nb.d[2], nb.d[1], sh);
         wd[2] = __builtin_amdgcn_alignbyte(nb.d[3], nb.d[2], sh);
@@ -851,10 +1031,6 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
         more = half_round(0, std::integral_constant<int, -1>{}, false);
         if (more) more = half_round(8, std::integral_constant<int, -1>{}, false);
       }
-    }
-    if (kPool && virt && !virt_fetch && __builtin_amdgcn_readfirstlane((int)__any(restart)) != 0) {  // wave-uniform
-      virt_fetch = true;
-      continue;  // the same round again, bytes from the stream
     }
 
     // ---- sessions with packets in flight give every packet a picture of its own: its unchanged (0xFF) blocks are
@@ -935,16 +1111,7 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
     if (live_blk) {
       const uint32_t off32 = block_offset(grp, dmb, kblk, mb);
       uint8_t* plane = outbuf + plane_off;  // wave-uniform; steps from row to row on the scalar side
-      // (the pooled blocks' round: the rows go back into the lane's scratch, whose coefficients the transform has
-      // read by then — but for the one form that reads the scratch twice, which holds its first four rows back)
-      uint32_t vrow = my_a;
       auto put_packed = [&](uint2 o) {  // one row of the block, already clamped and packed
-        if (kPool && virt && !virt_direct_l) {
-          *(lds_u32_t*)(uintptr_t)vrow = o.x;
-          *(lds_u32_t*)(uintptr_t)(vrow + 4u) = o.y;
-          vrow += 8u;
-          return;
-        }
         // nontemporal (global_store_dwordx2 ... nt): the picture is not read again by this kernel, and the
         // stores are what a short chroma round waits for (-3.5 % on the kernel, v21_nontemporal_stores_ab.txt)
         typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
@@ -972,101 +1139,7 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
       } else
 #endif
       if (lo) {
-        // rows 0-3 of the column pairs (0, 1) and (2, 3)
-        const uint4 qa = my[0], qb = my[2];
-        // anything in row 3 or column 3?  (the lanes of this branch: those with a live block)
-        const uint32_t t3 = qa.w | qb.w | ((qb.x | qb.y | qb.z) & 0xFFFF0000u);
-#ifdef MIRTJ_EXP_FIXED_PATHS
-        if (true || !__any(t3 != 0u)) {
-#else
-        if (!__any(t3 != 0u)) {
-#endif
-          // ---- three-input transform: columns 0-2 in, rows of three in ----
-#if MIRTJ_PK_IDCT
-          const bool fits = __all(pk_range_lo3(qa, qb, KP));
-          MIRTJ_STAMP(5);  // coordinates, scratch reads, 16-bit range test
-#ifdef MIRTJ_EXP_PK_ONLY
-          if (true) {
-#else
-          if (fits) {
-#endif
-            // two columns, then two rows, to a register (rtj_idct_pk.h)
-            uint32_t ya[8], yb[8];
-            idct8_pk_lo3_col<true>(qa.x, qa.y, qa.z, ya, KP);   // columns 0, 1
-            idct8_pk_lo3_col<false>(qb.x, qb.y, qb.z, yb, KP);  // columns 2, (3: zero)
-#pragma unroll
-            for (int r = 0; r < 8; r += 2) {
-              uint2 o0, o1;
-              idct8_pk_lo3_row_px(ya[r], ya[r + 1], yb[r], yb[r + 1], o0, o1, KP);
-              put_packed(o0);
-              put_packed(o1);
-            }
-          } else
-#endif
-#ifndef MIRTJ_EXP_PK_ONLY
-          {
-            int ws[8][3];
-#if MIRTJ_ASM_IDCT
-            {
-              int y[8];
-              idct8_lo3_col<true, false>(qa.x, qa.y, qa.z, y, K);
-#pragma unroll
-              for (int r = 0; r < 8; r++) ws[r][0] = y[r];
-              idct8_lo3_col<false, true>(qa.x, qa.y, qa.z, y, K);
-#pragma unroll
-              for (int r = 0; r < 8; r++) ws[r][1] = y[r];
-              idct8_lo3_col<false, false>(qb.x, qb.y, qb.z, y, K);
-#pragma unroll
-              for (int r = 0; r < 8; r++) ws[r][2] = y[r];
-            }
-#pragma unroll
-            for (int r = 0; r < 8; r++) put_packed(idct8_lo3_row_px(ws[r][0], ws[r][1], ws[r][2], K));
-#else
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-              const uint4& q = c < 2 ? qa : qb;
-              int x0 = half16(q.x, c & 1);
-              const int x1 = half16(q.y, c & 1), x2 = half16(q.z, c & 1);
-              if (c == 0) x0 += 4;  // DESCALE's rounding term, carried through both linear DC paths
-              int y[8];
-              idct8_lo3(x0, x1, x2, y);
-#pragma unroll
-              for (int r = 0; r < 8; r++) ws[r][c] = y[r];
-            }
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-              int y[8];
-              idct8_lo3(ws[r][0], ws[r][1], ws[r][2], y);
-              put_row(y);
-            }
-#endif
-          }
-#else
-          {}
-#endif  // MIRTJ_EXP_PK_ONLY
-        } else {
-          // ---- four-input transform: columns 0-3 in, rows of four in ----
-#ifndef MIRTJ_EXP_PK_ONLY
-          int ws[8][4];
-#pragma unroll
-          for (int c = 0; c < 4; c++) {
-            const uint4& q = c < 2 ? qa : qb;
-            int x0 = half16(q.x, c & 1);
-            const int x1 = half16(q.y, c & 1), x2 = half16(q.z, c & 1), x3 = half16(q.w, c & 1);
-            if (c == 0) x0 += 4;  // DESCALE's rounding term, carried through both linear DC paths
-            int y[8];
-            idct8_lo(x0, x1, x2, x3, y);
-#pragma unroll
-            for (int r = 0; r < 8; r++) ws[r][c] = y[r];
-          }
-#pragma unroll
-          for (int r = 0; r < 8; r++) {
-            int y[8];
-            idct8_lo(ws[r][0], ws[r][1], ws[r][2], ws[r][3], y);
-            put_row(y);
-          }
-#endif
-        }
+        lo_forms(put_packed);
       } else {
         bool packed = false;
 #if MIRTJ_PK_IDCT
@@ -1105,10 +1178,6 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
 #endif
 #ifndef MIRTJ_EXP_PK_ONLY
         if (!packed) {
-          // (in the pooled blocks' round this form, which reads the scratch twice, stores its rows itself, 8-byte pieces
-          // at the blocks' own places — blocks outside the 16-bit budget: no encoder makes them — and the home lanes
-          // leave the general blocks alone)
-          if (kPool && virt) virt_direct_l = true;
           // ---- column pass: column c is one half of the 16-byte pieces c & ~1 (rows 0-3) and (c & ~1) + 1 (rows 4-7) ----
           // Two rounds, rows 0-3 and rows 4-7, each with a column pass of its own: this path is the rare one (a block
           // outside the 16-bit budget), and 32 + 32 registers of column results are what the kernel's register count —
@@ -1165,49 +1234,6 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
 #endif  // MIRTJ_EXP_PK_ONLY
       }
     }
-    if (kPool && virt) {
-      const bool virt_direct = __any(virt_direct_l);  // wave-uniform (the form is chosen per wave)
-      // ---- the pooled rounds' rows leave now: DC-only blocks from the register, general ones from the scratch of the
-      //      lane that transformed them (one wave, LDS operations in order: the fences keep the compiler from reordering) ----
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll 1
-      for (uint32_t j = 0; j < npool; j++) {  // (wave-uniform; rolled: the rows of one round at a time in registers)
-        const uint32_t info = j == 0u ? pl_info01 & 0xFFFFu : j == 1u ? pl_info01 >> 16 : pl_info2;
-        const uint32_t cls = (info >> 8) & 3u;
-        if (cls != 0u && !(virt_direct && cls == 2u)) {
-          const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)(j == 0u ? pl_grp01 & 0xFFFFu : j == 1u ? pl_grp01 >> 16 : pl_grp2));
-          const uint32_t hdmb = (uint32_t)(lane & 31), hk = 4u + (uint32_t)(lane >> 5);
-          uint32_t o = block_offset(g, hdmb, hk, g * (uint32_t)kMbPerGroup + hdmb);
-          uint8_t* const plane = outbuf + plane_off;
-          const uint32_t fill = (info & 0xFFu) * 0x01010101u;
-          const uint32_t ra = lds_address(s_lds) + ((info >> 10) & 63u) * (uint32_t)(kCoefStride * 2);
-#pragma unroll 2
-          for (int r = 0; r < 8; r++) {
-            typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-            u32x2_t ov;
-            ov.x = fill;
-            ov.y = fill;
-            if (cls == 2u) {
-              ov.x = *(const lds_u32_t*)(uintptr_t)(ra + 8u * (uint32_t)r);
-              ov.y = *(const lds_u32_t*)(uintptr_t)(ra + 8u * (uint32_t)r + 4u);
-            }
-            __builtin_nontemporal_store(ov, (u32x2_t*)(plane + o));
-            o += stride;
-          }
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the scratch is written again by the next round's parse
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      npool = 0u;
-      pool_g = 0u;
-      virt = false;
-      virt_fetch = false;
-      if (virt_last) break;
-      continue;  // on with iteration `it`, whose bytes have been waiting in `cur`
-    }
     MIRTJ_STAMP(3);  // coordinates, transform, row stores
     if (!have_n) {
       if (kPool && npool != 0u) {  // the wave's last round is done: the pool's transform round, then out
@@ -1220,41 +1246,8 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
     // Every transform variant ends with kRowStores row stores, so behind the join "all but the kRowStores youngest
     // operations" is exactly "everything requested before the transform" — unless no lane had a live block: such a wave
     // stored nothing and waits for all there is.  (kRowStores sits next to the stores it counts: put_packed above.)
-    const uint32_t younger = __ballot(live_blk) != 0ull ? (uint32_t)kRowStores : 0u;  // (a pooling round stores nothing)
-    if (kPool) {
-      // The wait and the copies out of the registers being filled in ONE block: with this loop's control flow the
-      // compiler, given the registers as in/out operands of a wait block of its own (the form below), ties them to other
-      // registers and copies them IN FRONT of the wait (tools/check_async_loads.py found it).  Plain inputs need no
-      // copy, and what reads them stands behind the wait in the same text.
-      uint32_t c0, c1, c2, c3, c4, c5, c6, c7, c8, pn;
-      asm volatile(
-          "s_cmp_eq_u32 %20, 8\n\t"
-          "s_cbranch_scc1 .Lmirtj_w8_%=\n\t"
-          "s_waitcnt vmcnt(0)\n\t"
-          "s_branch .Lmirtj_arrived_%=\n"
-          ".Lmirtj_w8_%=:\n\t"
-          "s_waitcnt vmcnt(8)\n"
-          ".Lmirtj_arrived_%=:\n\t"
-          "v_mov_b32 %0, %10\n\tv_mov_b32 %1, %11\n\tv_mov_b32 %2, %12\n\tv_mov_b32 %3, %13\n\tv_mov_b32 %4, %14\n\t"
-          "v_mov_b32 %5, %15\n\tv_mov_b32 %6, %16\n\tv_mov_b32 %7, %17\n\tv_mov_b32 %8, %18\n\tv_mov_b32 %9, %19"
-          : "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&v"(c4), "=&v"(c5), "=&v"(c6), "=&v"(c7), "=&v"(c8), "=&v"(pn)
-          : "v"(nb0.x), "v"(nb0.y), "v"(nb0.z), "v"(nb0.w), "v"(nb1.x), "v"(nb1.y), "v"(nb1.z), "v"(nb1.w), "v"(nb2),
-            "v"(pos_nn), "s"(younger)
-          : "scc", "memory");
-      MIRTJ_STAMP(4);
-      pos0 = pos_n;
-      pos_n = pn;
-      if (inside_n) {
-        cur.d[0] = c0; cur.d[1] = c1; cur.d[2] = c2; cur.d[3] = c3; cur.d[4] = c4;
-        cur.d[5] = c5; cur.d[6] = c6; cur.d[7] = c7; cur.d[8] = c8;
-      } else {
-        cur = fetch(pos0, false, 9);
-      }
-    } else {
-    // Every transform variant ends with kRowStores row stores, so behind the join "all but the kRowStores youngest
-    // operations" is exactly "everything requested before the transform" — unless no lane had a live block: such a wave
-    // stored nothing and waits for all there is.  (kRowStores sits next to the stores it counts: put_packed above.)
     {
+      const uint32_t younger = __ballot(live_blk) != 0ull ? (uint32_t)kRowStores : 0u;  // (a pooling round stores nothing)
       asm volatile(
           "s_cmp_eq_u32 %4, 8\n\t"
           "s_cbranch_scc1 .Lmirtj_w8_%=\n\t"
@@ -1278,7 +1271,6 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
       cur.d[8] = nb2;
     } else {
       cur = fetch(pos0, false, 9);
-    }
     }
     inside = inside_n;
     it++;
