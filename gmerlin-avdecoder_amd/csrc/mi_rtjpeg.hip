@@ -18,6 +18,7 @@
 #include "../../include/mi_rtjpeg.h"
 #include "rtj_color_kernels.h"
 #include "rtj_common.h"
+#include "rtj_decode_chroma.h"
 #include "rtj_decode_kernels.h"
 #include "rtj_encode_kernels.h"
 #include "rtj_index_kernels.h"
@@ -97,6 +98,13 @@ struct mi_rtj_plan {
   uint32_t* d_spec_todo = nullptr;         // [n + 1]: count, then the packets left to the exact kernels
   int cap_spec_frames = 0;
   uint32_t* d_spec_state = nullptr;        // [2]: launches in a row that refused every packet, launches left paused
+  // batches: what k_decode_split leaves to k_decode_list (rtj_decode_kernels.h, DecList): every part of every group of a
+  // launch fits; two counters, launches alternate, a launch's k_decode_list zeroes the other one
+  uint2* d_declist = nullptr;
+  uint32_t* d_declist_cnt = nullptr;
+  uint64_t declist_cap = 0;
+  int declist_flip = 0;
+  int split = -1;                          // MI_RTJ_SPLIT (A/B): 0 = batches run k_decode<true, false> as in round 3
   int rotate = -1;                         // MI_RTJ_ROTATE: 1 / 0 = a k_decode wave takes all three parts of its groups / one part; -1 = by batch size
   const uint8_t* prev_pic = nullptr;       // sessions: where unchanged blocks of this launch are copied from
   hipStream_t idx_stream = nullptr;        // the stream of the index kernels (sessions: theirs, not owned; batches: own_idx); null = the instance's
@@ -550,7 +558,39 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out, int what = kL
     uint8_t* const out8 = (uint8_t*)d_out;
     // four instantiations: (a wave takes all three parts of its groups | one part) x (unchanged blocks stay | are
     // fetched from the previous packet's picture); a launch runs the one that carries nothing else
-    if (span == 3u) {
+    if (span == 3u && !p->prev_pic && p->split != 0) {
+      // batches: luma waves (two parts of their groups in turn) and chroma waves that pool three groups' busy blocks
+      // into one transform round; what neither covers goes to the list and k_decode_list (rtj_decode_chroma.h)
+      const uint64_t need = 3ull * drows * p->max_groups;
+      if (p->declist_cap < need) {
+        HIPCHK(c, hipStreamSynchronize(ds));
+        if (p->d_declist) (void)hipFree(p->d_declist);
+        p->d_declist = nullptr;
+        p->declist_cap = 0;
+        if (need > 0xFFFFFFFFull) return fail(c, MI_RTJ_ERR_ARG, "plan too large: %llu group parts", (unsigned long long)need);
+        HIPCHK(c, hipMalloc((void**)&p->d_declist, sizeof(uint2) * need));
+        p->declist_cap = need;
+      }
+      if (!p->d_declist_cnt) {
+        HIPCHK(c, hipMalloc((void**)&p->d_declist_cnt, 2 * sizeof(uint32_t)));
+        HIPCHK(c, hipMemsetAsync(p->d_declist_cnt, 0, 2 * sizeof(uint32_t), ds));
+      }
+      const DecList list{p->d_declist_cnt + p->declist_flip, p->d_declist, (uint32_t)p->declist_cap};
+      const uint32_t slots_c = chroma_pool_slots(p->max_groups);
+#ifdef MIRTJ_EXPERIMENTS  // timing builds only (wrong pictures): MI_RTJ_SPLIT_ONLY = 1 the luma waves alone, 2 the chroma waves alone
+      if (const char* only = getenv("MI_RTJ_SPLIT_ONLY")) {
+        if (atoi(only) == 1)
+          hipLaunchKernelGGL(k_decode_split, dim3(dslots, drows), block, 0, ds, dfr, st, c->d_lut, blk, out8, dslots, list);
+        else
+          hipLaunchKernelGGL(k_decode_split, dim3(slots_c, drows), block, 0, ds, dfr, st, c->d_lut, blk, out8, 0u, list);
+      } else
+#endif
+      hipLaunchKernelGGL(k_decode_split, dim3(dslots + slots_c, drows), block, 0, ds, dfr, st, c->d_lut, blk, out8,
+                         dslots, list);
+      hipLaunchKernelGGL(k_decode_list, dim3(kDecListGrid), block, 0, ds, dfr, st, c->d_lut, blk, out8, list,
+                         p->d_declist_cnt + (p->declist_flip ^ 1));
+      p->declist_flip ^= 1;
+    } else if (span == 3u) {
       if (p->prev_pic)
         hipLaunchKernelGGL((k_decode<true, true>), grid, block, 0, ds, dfr, st, c->d_lut, blk, out8,
                            p->prev_pic);
@@ -770,6 +810,8 @@ mi_rtj_plan* mi_rtj_plan_create(mi_rtj_ctx* c, int n, const uint8_t* headers, co
     p->dec_slots = ds ? (uint32_t)atoi(ds) : 0u;
     const char* ro = getenv("MI_RTJ_ROTATE");
     p->rotate = ro ? (atoi(ro) != 0) : -1;
+    const char* spl = getenv("MI_RTJ_SPLIT");
+    p->split = spl ? (atoi(spl) != 0) : -1;
   }
   if (hipSetDevice(c->device) != hipSuccess || plan_alloc_chunks(p) != MI_RTJ_OK) {
     mi_rtj_plan_destroy(p);
@@ -839,6 +881,8 @@ void mi_rtj_plan_destroy(mi_rtj_plan* p) {
     (void)hipStreamDestroy(p->own_idx);
   }
   if (p->d_blkoff_b) (void)hipFree(p->d_blkoff_b);
+  if (p->d_declist) (void)hipFree(p->d_declist);
+  if (p->d_declist_cnt) (void)hipFree(p->d_declist_cnt);
   for (hipEvent_t e : p->e_read)
     if (e) (void)hipEventDestroy(e);
   delete p;

@@ -383,9 +383,6 @@ constexpr int kDecThreads = 64;
 #ifndef MIRTJ_DEC_ITERS
 #define MIRTJ_DEC_ITERS 11
 #endif
-#ifndef MIRTJ_CHROMA_POOL
-#define MIRTJ_CHROMA_POOL 0
-#endif
 constexpr int kCoefStride = MIRTJ_COEF_STRIDE;  // int16 per lane: 64 + 8 pad (144 B, conflict-free b128 reads)
 constexpr int kDecIters = MIRTJ_DEC_ITERS;      // macroblock groups a wave works through, one after the other (at most)
 constexpr int kSlotTabN = 64 + 16;              // slot table: 64 coefficient slots, then "block finished" entries
@@ -461,52 +458,167 @@ constexpr int kCoefWords = kDecThreads * kCoefStride / 2;
 #endif
 constexpr int kDecLdsWords = kCoefWords + 2 * kSlotTabN + MIRTJ_DEC_LDS_PAD;  // scratch, luma slot table, chroma slot table
 
-#ifdef MIRTJ_STAMPS  // diagnostic build: where a wave's time goes (shader cycles per section, summed over all waves)
-__device__ unsigned long long g_stamps[16];  // [0..6] luma iterations, [8..14] chroma iterations; [7] waves
-#define MIRTJ_STAMP(i)                                              \
-  do {                                                              \
-    const unsigned long long t_ = __builtin_amdgcn_s_memtime();     \
-    if (chroma) st_c[i] += t_ - st_last;                            \
-    else st_y[i] += t_ - st_last;                                   \
-    st_last = t_;                                                   \
-  } while (0)
-#else
-#define MIRTJ_STAMP(i) \
-  do {                 \
-  } while (0)
+
+
+// ---------------------------------------------------------------------------------------
+// What k_decode leaves to k_decode_list: (frame row of the launch, group | part << 28).  A wave of the batch
+// instantiation that meets a block outside the packed passes' 16-bit budget (rtj_idct_pk.h: no legal picture has one),
+// and a pooling chroma wave that meets a group its short forms do not cover, append the WHOLE part of the group here
+// and store nothing of it; k_decode_list then decodes those parts with the one-value-per-register passes — whole
+// parts, so whole row segments (partial-line writes are what made round 2's deferred blocks slow).  The capacity is
+// every part of every group of the launch: the list cannot overflow.
+// ---------------------------------------------------------------------------------------
+struct DecList {
+  uint32_t* count;
+  uint2* items;
+  uint32_t cap;
+};
+__device__ __forceinline__ void declist_push(const DecList& L, uint32_t fidx, uint32_t grp, uint32_t part) {
+  // called by the lanes of a (possibly divergent) branch with wave-uniform arguments: the first active lane appends
+  const unsigned long long m = __ballot(1);
+  if ((uint32_t)threadIdx.x == (uint32_t)__builtin_ctzll(m)) {
+    const uint32_t i = atomicAdd(L.count, 1u);
+    if (i < L.cap) L.items[i] = make_uint2(fidx, grp | (part << 28));
+  }
+}
+
+// a wave-uniform pointer, told to the compiler: the hand-issued loads take their bases from scalar registers, and a
+// value loaded from memory the kernel also writes (the list's entries, a descriptor behind an atomic) is not known to
+// be uniform otherwise
+template <class T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+  const uint64_t v = (uint64_t)(uintptr_t)p;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return (T*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+
+__device__ __forceinline__ int half16(uint32_t w, int odd) { return odd ? (int)w >> 16 : (int)(int16_t)(w & 0xFFFFu); }
+
+// The transform's forms for blocks with nothing outside the low 4x4 (three-input, packed or not; four-input): `my` is
+// the lane's coefficient scratch, the eight rows are handed to `putp` (clamped and packed, row 0 first).  Called by the
+// lanes that have a live block; which form runs is decided per wave (ballots over those lanes).
+template <class Put>
+__device__ __forceinline__ void transform_lo(const uint4* my, const IdctK& K, const IdctPK& KP, Put&& putp) {
+  auto putr = [&](const int (&y)[8]) {
+    uint2 o;
+    o.x = lshl_or(lshl_or(px(y[3]), 8, px(y[2])), 16, lshl_or(px(y[1]), 8, px(y[0])));
+    o.y = lshl_or(lshl_or(px(y[7]), 8, px(y[6])), 16, lshl_or(px(y[5]), 8, px(y[4])));
+    putp(o);
+  };
+  (void)putr;
+  // rows 0-3 of the column pairs (0, 1) and (2, 3)
+  const uint4 qa = my[0], qb = my[2];
+  // anything in row 3 or column 3?
+  const uint32_t t3 = qa.w | qb.w | ((qb.x | qb.y | qb.z) & 0xFFFF0000u);
+  if (!__any(t3 != 0u)) {
+    // ---- three-input transform: columns 0-2 in, rows of three in ----
+#if MIRTJ_PK_IDCT
+    const bool fits = __all(pk_range_lo3(qa, qb, KP));
+    if (fits) {
+      // two columns, then two rows, to a register (rtj_idct_pk.h)
+      uint32_t ya[8], yb[8];
+      idct8_pk_lo3_col<true>(qa.x, qa.y, qa.z, ya, KP);   // columns 0, 1
+      idct8_pk_lo3_col<false>(qb.x, qb.y, qb.z, yb, KP);  // columns 2, (3: zero)
+#pragma unroll
+      for (int r = 0; r < 8; r += 2) {
+        uint2 o0, o1;
+        idct8_pk_lo3_row_px(ya[r], ya[r + 1], yb[r], yb[r + 1], o0, o1, KP);
+        putp(o0);
+        putp(o1);
+      }
+    } else
 #endif
+    {
+      int ws[8][3];
+#if MIRTJ_ASM_IDCT
+      {
+        int y[8];
+        idct8_lo3_col<true, false>(qa.x, qa.y, qa.z, y, K);
+#pragma unroll
+        for (int r = 0; r < 8; r++) ws[r][0] = y[r];
+        idct8_lo3_col<false, true>(qa.x, qa.y, qa.z, y, K);
+#pragma unroll
+        for (int r = 0; r < 8; r++) ws[r][1] = y[r];
+        idct8_lo3_col<false, false>(qb.x, qb.y, qb.z, y, K);
+#pragma unroll
+        for (int r = 0; r < 8; r++) ws[r][2] = y[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 8; r++) putp(idct8_lo3_row_px(ws[r][0], ws[r][1], ws[r][2], K));
+#else
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        const uint4& q = c < 2 ? qa : qb;
+        int x0 = half16(q.x, c & 1);
+        const int x1 = half16(q.y, c & 1), x2 = half16(q.z, c & 1);
+        if (c == 0) x0 += 4;  // DESCALE's rounding term, carried through both linear DC paths
+        int y[8];
+        idct8_lo3(x0, x1, x2, y);
+#pragma unroll
+        for (int r = 0; r < 8; r++) ws[r][c] = y[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        int y[8];
+        idct8_lo3(ws[r][0], ws[r][1], ws[r][2], y);
+        putr(y);
+      }
+#endif
+    }
+  } else {
+    // ---- four-input transform: columns 0-3 in, rows of four in ----
+    int ws[8][4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const uint4& q = c < 2 ? qa : qb;
+      int x0 = half16(q.x, c & 1);
+      const int x1 = half16(q.y, c & 1), x2 = half16(q.z, c & 1), x3 = half16(q.w, c & 1);
+      if (c == 0) x0 += 4;  // DESCALE's rounding term, carried through both linear DC paths
+      int y[8];
+      idct8_lo(x0, x1, x2, x3, y);
+#pragma unroll
+      for (int r = 0; r < 8; r++) ws[r][c] = y[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      int y[8];
+      idct8_lo(ws[r][0], ws[r][1], ws[r][2], ws[r][3], y);
+      putr(y);
+    }
+  }
+}
 
 // vector-memory stores every transform variant of decode_wave issues per live wave and iteration (eight rows of 8 bytes
 // per lane); the counted wait behind them is written for exactly this number
 constexpr int kRowStores = 8;
 static_assert(kRowStores == 8, "the wait block of decode_wave spells vmcnt(8)");
-// kRot: a wave takes all three parts of its groups in turn (span 3, batches) / one part (span 1).  kPrev: sessions —
-// unchanged (0xFF) blocks are copied from the previous packet's picture.  Both are compile-time: the instantiation a
-// batch launch runs carries nothing of the other forms (the kernel is short of scalar registers as it is).
-// (Round 2 also held a run-time switched "put the busy blocks of mostly-flat groups off to a second kernel" path
-// here; it was slower — partial-line writes, DESIGN.md — and is gone from the tree.)
-template <bool kRot, bool kPrev>
+// kRot: a wave takes kParts parts of its groups in turn, starting with part0 (kParts = 3: the batches of round 2 and 3;
+// kParts = 2: the luma waves of a batch whose chroma parts go to pooling waves, rtj_decode_chroma.h) / one part (span 1).
+// kPrev: sessions — unchanged (0xFF) blocks are copied from the previous packet's picture.  kList: a wave that meets a
+// block outside the packed passes' 16-bit budget leaves its part of the group to k_decode_list (DecList above) instead
+// of running the one-value-per-register passes itself: those passes size the register file of every path (108 vector
+// registers with them, 4 waves per SIMD).  All compile-time: the instantiation a batch launch runs carries nothing of
+// the other forms.  The wave is told what it works on (frame row `fidx`, `slot` of `slots`, first part `part0`) by its
+// kernel.
+template <bool kRot, bool kPrev, int kParts, bool kList>
 __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const FrameDev* __restrict__ frames,
-                                            const uint8_t* __restrict__ stream, const QTab* __restrict__ lut,
-                                            const uint32_t* __restrict__ blkoff, uint8_t* __restrict__ outbuf,
-                                            const uint8_t* __restrict__ prev) {
+                                            const uint32_t fidx, const uint32_t slot, const uint32_t slots,
+                                            const uint32_t part0, const uint8_t* __restrict__ stream,
+                                            const QTab* __restrict__ lut, const uint32_t* __restrict__ blkoff,
+                                            uint8_t* __restrict__ outbuf, const uint8_t* __restrict__ prev,
+                                            const DecList list) {
   uint32_t* s_tab = s_lds + kCoefWords;
 
-  const FrameDev f = frames[blockIdx.y];
-  // span == 1: a wave owns ONE part of its groups; grid.x = 3 * slots, numbered slot-major: the three parts of a slot
-  // are dispatched one after the other and (workgroups are dealt round-robin to the 8 XCDs) land on different XCDs —
-  // see decode_slots().  span == 3: a wave takes all three parts of its groups in turn (grid.x = slots), so a group's
-  // stream bytes and block offsets come over the fabric once instead of three times.
+  const FrameDev f = frames[fidx];
+  // One part per wave (span 1): the three parts of a slot are dispatched one after the other and (workgroups are dealt
+  // round-robin to the 8 XCDs) land on different XCDs — see decode_slots().  Several parts per wave: a group's stream
+  // bytes and block offsets come over the fabric once.
   constexpr bool rot = kRot;
-  const uint32_t slots = rot ? gridDim.x : gridDim.x / 3u;
-  const uint32_t slot = rot ? blockIdx.x : blockIdx.x / 3u, part0 = rot ? 0u : blockIdx.x - slot * 3u;
   const uint32_t ngroups = (f.nmb + (uint32_t)kMbPerGroup - 1u) / (uint32_t)kMbPerGroup;
   if (slot >= ngroups) return;
-#ifdef MIRTJ_EXP_ONLY_PART  // experiment builds (tools/pmc_parts.sh): 2 = only the chroma part works, 0 = only the luma parts
-  if (!rot && (MIRTJ_EXP_ONLY_PART == 2) != (part0 == 2u)) return;
-#endif
   const int lane = threadIdx.x;
-  const uint32_t* off = blkoff + f.blk_base;
+  const uint32_t* off = uniform_ptr(blkoff + f.blk_base);
   const QTab& qt = lut[f.qidx];
   {
     const int nat = c_zz[lane];
@@ -528,7 +640,7 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
   uint32_t bt8 = chroma ? bt8_c : bt8_y;
   uint32_t tab_a = lds_address(s_tab) + (chroma ? 4u * (uint32_t)kSlotTabN : 0u);
   int ca_end = (int)tab_a + 4 * 64;  // slot counter (see below) of a finished block
-  const uint8_t* data = stream + f.data_off;
+  const uint8_t* data = uniform_ptr(stream + f.data_off);
   // iteration `it` of this wave: which group, which block of it, and is there one (per lane)
   struct Src {
     uint32_t grp, dmb, kblk, mb, part;  // part: wave-uniform
@@ -539,8 +651,8 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
     uint32_t g = it;
     r.part = part0;
     if (rot) {
-      g = it / 3u;
-      r.part = it - 3u * g;
+      g = it / (uint32_t)kParts;
+      r.part = part0 + it - (uint32_t)kParts * g;
     }
     r.grp = slot + g * slots;
     r.dmb = r.part == 2u ? (uint32_t)(lane & 31) : (uint32_t)(lane >> 1);
@@ -550,7 +662,7 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
     return r;
   };
   auto more_after = [&](uint32_t it) -> bool {  // wave-uniform: is there an iteration it + 1
-    const uint32_t g = rot ? (it + 1u) / 3u : it + 1u;
+    const uint32_t g = rot ? (it + 1u) / (uint32_t)kParts : it + 1u;
     return g < (uint32_t)kDecIters && slot + g * slots < ngroups;
   };
 
@@ -622,9 +734,6 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
                   : (16u * my_ + 8u * (kblk >> 1)) * stride + 16u * mx + 8u * (kblk & 1u);
   };
 
-#ifdef MIRTJ_STAMPS
-  unsigned long long st_y[7] = {0, 0, 0, 0, 0, 0, 0}, st_c[7] = {0, 0, 0, 0, 0, 0, 0}, st_last = __builtin_amdgcn_s_memtime();
-#endif
   // (which block a lane has in an iteration is worked out afresh where it is needed — a handful of instructions —
   // instead of being carried from iteration to iteration in vector registers: the register count decides how many
   // waves a SIMD holds)
@@ -640,256 +749,9 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
   asm volatile("" ::"v"(cur.d[0]), "v"(cur.d[1]), "v"(cur.d[2]), "v"(cur.d[3]), "v"(cur.d[4]), "v"(cur.d[5]),
                "v"(cur.d[6]), "v"(cur.d[7]), "v"(cur.d[8]), "v"(pos_n));
 
-  // ---- pooled chroma rounds (kPool, -DMIRTJ_CHROMA_POOL=1; batch launches without `prev`; second form of the prototype) ----
-  // At high quality most chroma blocks are "DC, run of 63": 64 equal pixels.  A chroma round (64 blocks) then only
-  // CLASSIFIES its blocks: a lane keeps the pixel value and the class of its block (16 bits per pooled round) and, when
-  // its block is a general one, puts the block's first eight stream bytes into the 12 free bytes of the coefficient
-  // scratch of lane k, k = the block's rank among the general blocks pooled so far.  When enough have come together (or
-  // the wave runs out of work) ONE transform round runs over them — a block of its own at the top of the loop, with the
-  // short forms of the transform only — and then the home lanes of the pooled rounds store their rows, DC-only ones from
-  // the register, general ones from the scratch: whole row segments, as in a plain round.  Pooled blocks the short forms
-  // do not cover (longer than eight bytes, coefficients outside the low 4x4: no encoder makes such chroma at these
-  // qualities) send the wave BACK to the first pooled round, to run everything from there again without pooling.
-  constexpr bool kPool = kRot && !kPrev && (MIRTJ_CHROMA_POOL != 0);
-  constexpr uint32_t kPoolSlots = 3;       // pooled rounds at most (17 general blocks a round on the bench content)
-  constexpr uint32_t kPoolFlushFrom = 40;  // general blocks pooled from which the transform round runs next
-#ifdef MIRTJ_POOL_OFF
-  const bool pool_on = false;
-#else
-  const bool pool_on = kPool && bt8_c == 0u;  // (tables with raw chroma bytes: every round is a plain one)
-#endif
-  // What a lane keeps per pooled round — pixel | class << 8 | rank << 10 (class 0 nothing to store, 1 DC only, 2 general) —
-  // lives in bytes 130..135 of its coefficient scratch (three rounds of 16 bits), the rounds' groups and the iteration
-  // of the first pooled round in spare entries of the luma slot table (entries past 64 are never read by the parse):
-  // the kernel has neither vector nor scalar registers to spare.
-  const uint32_t pool_tab = lds_address(s_tab) + 4u * 70u;  // [0..2] groups, [3] first pooled iteration, [4] no pooling before this iteration
-  uint32_t npool = 0, pool_g = 0;        // wave-uniform: rounds pooled, general blocks pooled
-  if (kPool && lane == 0) *(lds_u32_t*)(uintptr_t)(pool_tab + 16u) = 0u;
-  bool virt = false, virt_last = false;  // wave-uniform: the pooled blocks' transform round runs next (and is the wave's last act)
-  const IdctK K{362, 473, -669, 277, 128, 235};
-  const IdctPK KP = idct_pk_constants();
-  auto half16 = [](uint32_t w, int odd) -> int { return odd ? (int)w >> 16 : (int)(int16_t)(w & 0xFFFFu); };
-  // the transform's forms for blocks inside the low 4x4 (three-input, packed or not; four-input), rows handed to `putp`
-  auto lo_forms = [&](auto&& putp) {
-    auto putr = [&](const int (&y)[8]) {
-      uint2 o;
-      o.x = lshl_or(lshl_or(px(y[3]), 8, px(y[2])), 16, lshl_or(px(y[1]), 8, px(y[0])));
-      o.y = lshl_or(lshl_or(px(y[7]), 8, px(y[6])), 16, lshl_or(px(y[5]), 8, px(y[4])));
-      putp(o);
-    };
-    (void)putr;
-        // rows 0-3 of the column pairs (0, 1) and (2, 3)
-        const uint4 qa = my[0], qb = my[2];
-        // anything in row 3 or column 3?  (the lanes of this branch: those with a live block)
-        const uint32_t t3 = qa.w | qb.w | ((qb.x | qb.y | qb.z) & 0xFFFF0000u);
-#ifdef MIRTJ_EXP_FIXED_PATHS
-        if (true || !__any(t3 != 0u)) {
-#else
-        if (!__any(t3 != 0u)) {
-#endif
-          // ---- three-input transform: columns 0-2 in, rows of three in ----
-#if MIRTJ_PK_IDCT
-          const bool fits = __all(pk_range_lo3(qa, qb, KP));
-          MIRTJ_STAMP(5);  // coordinates, scratch reads, 16-bit range test
-#ifdef MIRTJ_EXP_PK_ONLY
-          if (true) {
-#else
-          if (fits) {
-#endif
-            // two columns, then two rows, to a register (rtj_idct_pk.h)
-            uint32_t ya[8], yb[8];
-            idct8_pk_lo3_col<true>(qa.x, qa.y, qa.z, ya, KP);   // columns 0, 1
-            idct8_pk_lo3_col<false>(qb.x, qb.y, qb.z, yb, KP);  // columns 2, (3: zero)
-#pragma unroll
-            for (int r = 0; r < 8; r += 2) {
-              uint2 o0, o1;
-              idct8_pk_lo3_row_px(ya[r], ya[r + 1], yb[r], yb[r + 1], o0, o1, KP);
-              putp(o0);
-              putp(o1);
-            }
-          } else
-#endif
-#ifndef MIRTJ_EXP_PK_ONLY
-          {
-            int ws[8][3];
-#if MIRTJ_ASM_IDCT
-            {
-              int y[8];
-              idct8_lo3_col<true, false>(qa.x, qa.y, qa.z, y, K);
-#pragma unroll
-              for (int r = 0; r < 8; r++) ws[r][0] = y[r];
-              idct8_lo3_col<false, true>(qa.x, qa.y, qa.z, y, K);
-#pragma unroll
-              for (int r = 0; r < 8; r++) ws[r][1] = y[r];
-              idct8_lo3_col<false, false>(qb.x, qb.y, qb.z, y, K);
-#pragma unroll
-              for (int r = 0; r < 8; r++) ws[r][2] = y[r];
-            }
-#pragma unroll
-            for (int r = 0; r < 8; r++) putp(idct8_lo3_row_px(ws[r][0], ws[r][1], ws[r][2], K));
-#else
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-              const uint4& q = c < 2 ? qa : qb;
-              int x0 = half16(q.x, c & 1);
-              const int x1 = half16(q.y, c & 1), x2 = half16(q.z, c & 1);
-              if (c == 0) x0 += 4;  // DESCALE's rounding term, carried through both linear DC paths
-              int y[8];
-              idct8_lo3(x0, x1, x2, y);
-#pragma unroll
-              for (int r = 0; r < 8; r++) ws[r][c] = y[r];
-            }
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-              int y[8];
-              idct8_lo3(ws[r][0], ws[r][1], ws[r][2], y);
-              putr(y);
-            }
-#endif
-          }
-#else
-          {}
-#endif  // MIRTJ_EXP_PK_ONLY
-        } else {
-          // ---- four-input transform: columns 0-3 in, rows of four in ----
-#ifndef MIRTJ_EXP_PK_ONLY
-          int ws[8][4];
-#pragma unroll
-          for (int c = 0; c < 4; c++) {
-            const uint4& q = c < 2 ? qa : qb;
-            int x0 = half16(q.x, c & 1);
-            const int x1 = half16(q.y, c & 1), x2 = half16(q.z, c & 1), x3 = half16(q.w, c & 1);
-            if (c == 0) x0 += 4;  // DESCALE's rounding term, carried through both linear DC paths
-            int y[8];
-            idct8_lo(x0, x1, x2, x3, y);
-#pragma unroll
-            for (int r = 0; r < 8; r++) ws[r][c] = y[r];
-          }
-#pragma unroll
-          for (int r = 0; r < 8; r++) {
-            int y[8];
-            idct8_lo(ws[r][0], ws[r][1], ws[r][2], ws[r][3], y);
-            putr(y);
-          }
-#endif
-        }
-  };
 
-  MIRTJ_STAMP(0);  // prologue: descriptor, table, first offsets and bytes
+  uint32_t exit_grp = ~0u, exit_part = 0u;  // (kList) the last round's part goes to the list: appended behind the loop
   for (uint32_t it = 0;;) {
-    if (kPool) virt = __builtin_amdgcn_readfirstlane((int)virt) != 0;
-    if (kPool && virt) {
-      // ---- the pooled blocks' transform round ----
-      const bool vlive = (uint32_t)lane < pool_g;
-      const uint32_t tab_c = lds_address(s_tab) + 4u * (uint32_t)kSlotTabN;
-      const int cend = (int)tab_c + 4 * 64;
-      bool unfinished = false;
-      uint32_t hi = 0u;
-      if (vlive) {
-        const uint32_t w0 = *(const lds_u32_t*)(uintptr_t)(my_a + 136u), w1 = *(const lds_u32_t*)(uintptr_t)(my_a + 140u);
-        {
-          uint4* z = (uint4*)my;
-#pragma unroll
-          for (int i = 0; i < 8; i++) z[i] = make_uint4(0, 0, 0, 0);
-        }
-        const uint32_t e0 = *(const lds_u32_t*)(uintptr_t)tab_c;
-        *(lds_i16_t*)(uintptr_t)(my_a + (uint32_t)slot_byte(0)) = (int16_t)mul_byte_hi16(w0, e0, 0, false);
-        int ca = (int)tab_c + 4;
-        int svb[7];
-        uint32_t e[7];
-#pragma unroll
-        for (int k = 1; k < 8; k++) {
-          const uint32_t w = k < 4 ? w0 : w1;
-          svb[k - 1] = sbyte_minus(w, k & 3, k63);
-          e[k - 1] = *(const lds_u32_t*)(uintptr_t)(uint32_t)ca;
-          ca = med3_i32(ca + 4, (svb[k - 1] << 2) + ca, cend);
-        }
-#pragma unroll
-        for (int k = 1; k < 8; k++) {
-          const uint32_t w = k < 4 ? w0 : w1;
-          int prod = mul_byte_hi16(w, e[k - 1], k & 3, true);
-          prod = svb[k - 1] > 0 ? 0 : prod;
-          *(lds_i16_t*)(uintptr_t)(my_a + (e[k - 1] & 0xFFFFu)) = (int16_t)prod;
-        }
-        unfinished = ca < cend;  // the block goes on behind its eighth byte
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-          if (i == 0 || i == 2) continue;  // rows 0-3 of columns 0-3
-          const uint4 q = my[i];
-          hi |= q.x | q.y | q.z | q.w;
-        }
-      }
-      const bool bail = __builtin_amdgcn_readfirstlane((int)__any(unfinished || hi != 0u)) != 0;  // wave-uniform
-      if (!bail) {
-        chroma = 1;
-        plane_off = f.out_off + ysz;
-        stride = f.w >> 1;
-        if (vlive) {
-          uint32_t vrow = my_a;  // the rows go back into the lane's scratch (its coefficients are in registers by then)
-          auto put_lds = [&](uint2 o) {
-            *(lds_u32_t*)(uintptr_t)vrow = o.x;
-            *(lds_u32_t*)(uintptr_t)(vrow + 4u) = o.y;
-            vrow += 8u;
-          };
-          lo_forms(put_lds);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (one wave, LDS operations in order: for the compiler)
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // the pooled rounds' rows leave now
-#pragma unroll 1
-        for (uint32_t j = 0; j < npool; j++) {
-          const uint32_t info = *(const __attribute__((address_space(3))) uint16_t*)(uintptr_t)(my_a + 130u + 2u * j);
-          const uint32_t cls = (info >> 8) & 3u;
-          if (cls != 0u) {
-            const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const lds_u32_t*)(uintptr_t)(pool_tab + 4u * j));
-            const uint32_t hdmb = (uint32_t)(lane & 31), hk = 4u + (uint32_t)(lane >> 5);
-            const uint32_t o = block_offset(g, hdmb, hk, g * (uint32_t)kMbPerGroup + hdmb);
-            uint8_t* plane = outbuf + plane_off;  // wave-uniform; steps from row to row on the scalar side
-            const uint32_t fill = (info & 0xFFu) * 0x01010101u;
-            uint32_t ra = lds_address(s_lds) + ((info >> 10) & 63u) * (uint32_t)(kCoefStride * 2);
-#pragma unroll 1
-            for (int r = 0; r < 8; r++) {
-              typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-              u32x2_t ov;
-              ov.x = fill;
-              ov.y = fill;
-              if (cls == 2u) {
-                ov.x = *(const lds_u32_t*)(uintptr_t)ra;
-                ov.y = *(const lds_u32_t*)(uintptr_t)(ra + 4u);
-              }
-              __builtin_nontemporal_store(ov, (u32x2_t*)(plane + o));
-              plane += stride;
-              ra += 8u;
-            }
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the scratch is written again by the next round's parse
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        npool = 0u;
-        pool_g = 0u;
-        virt = false;
-        if (virt_last) break;
-        continue;  // on with iteration `it`, whose bytes have been waiting in `cur`
-      }
-      // ---- the way back: from the first pooled round on, everything again, plain ----
-      if (lane == 0) *(lds_u32_t*)(uintptr_t)(pool_tab + 16u) = virt_last ? it + 1u : it;
-      it = (uint32_t)__builtin_amdgcn_readfirstlane((int)*(const lds_u32_t*)(uintptr_t)(pool_tab + 12u));
-      npool = 0u;
-      pool_g = 0u;
-      virt = false;
-      virt_last = false;
-      {
-        const Src r0 = source(it), r1 = source(it + 1u);
-        pos0 = off[r0.valid ? 6u * r0.mb + r0.kblk : 0u];
-        pos_n = off[r1.valid ? 6u * r1.mb + r1.kblk : 0u];
-        pos0 = r0.valid ? pos0 : 0u;
-        inside = !kForceGenericPaths && __all(pos0 + kFetchSpan <= f.data_len);
-        cur = fetch(pos0, inside, 9);
-      }
-      continue;
-    }
     const bool have_n = more_after(it);  // wave-uniform
     const Src s0 = source(it);
     const bool valid = s0.valid, valid_n = have_n && source(it + 1u).valid;
@@ -910,43 +772,10 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
     const uint32_t first4 = __builtin_amdgcn_alignbyte(d1, d0, sh);
     const bool live_any = valid && (first4 & 0xFFu) != 0xFFu;
 
-    // a chroma round of a pooling wave: classify, keep, store nothing yet
-    bool pool_it = false;
-    if (kPool && pool_on && chroma && it >= *(const lds_u32_t*)(uintptr_t)(pool_tab + 16u)) {
-      const uint32_t b1 = (first4 >> 8) & 0xFFu;
-      const uint32_t cls = !live_any ? 0u : b1 == 126u ? 1u : 2u;  // 126: a run of 63 slots behind the DC
-      const unsigned long long gm = __ballot(cls == 2u);
-      const uint32_t cnt = (uint32_t)__popcll(gm);
-      pool_it = __builtin_amdgcn_readfirstlane((int)(npool < kPoolSlots && pool_g + cnt <= 64u)) != 0;  // (else: a plain round)
-      if (pool_it) {
-        const uint32_t k = pool_g + (uint32_t)__popcll(gm & ((1ull << lane) - 1ull));
-        // the pixel of a DC-only block: what the transform makes of a lone DC (idct8_lo3(x0, 0, 0) is x0 in both passes)
-        const uint32_t q0 = *(const lds_u32_t*)(uintptr_t)tab_a >> 16;  // the DC's dequantiser (slot 0 of the chroma table)
-        const int dc = (int)(int16_t)((first4 & 0xFFu) * q0);
-        const uint32_t info = px(dc + 4) | (cls << 8) | ((k & 63u) << 10);
-        if (cls == 2u) {  // into lane k's scratch, bytes 136..143 (the coefficients end at 128, the dump is 128..129)
-          const uint32_t ea = lds_address(s_lds) + k * (uint32_t)(kCoefStride * 2);
-          *(lds_u32_t*)(uintptr_t)(ea + 136u) = first4;
-          *(lds_u32_t*)(uintptr_t)(ea + 140u) = __builtin_amdgcn_alignbyte(d2, d1, sh);
-        }
-        *(__attribute__((address_space(3))) uint16_t*)(uintptr_t)(my_a + 130u + 2u * npool) = (uint16_t)info;
-        if (lane == 0) {
-          *(lds_u32_t*)(uintptr_t)(pool_tab + 4u * npool) = grp;
-          if (npool == 0u) *(lds_u32_t*)(uintptr_t)(pool_tab + 12u) = it;
-        }
-        npool++;
-        pool_g += cnt;
-      }
-    }
-    const bool live_blk = live_any && !pool_it;  // the lanes of this iteration's transform round
+    const bool live_blk = live_any;  // the lanes of this iteration's transform round
+    bool rows_stored = true;         // (kList) false: the part was left to k_decode_list
 
-    // (-DMIRTJ_EXP_NO_PARSE / -DMIRTJ_EXP_NO_TRANSFORM: census builds for the instruction budget of DESIGN.md section 8 —
-    // wrong pictures, counted with rocprofv3 --pmc SQ_INSTS_VALU, never shipped)
-#ifdef MIRTJ_EXP_NO_PARSE
-    if (false) {
-#else
     if (live_blk) {
-#endif
       // ---- stream -> dequantised coefficients, int16, transposed (lib/RTjpeg.c:157-186) ----
       // The block's bytes are consumed 16 at a time from registers (aligned dwords + a byte funnel
       // shift), eight to a half round so that short blocks stop early.  The only loop-carried value
@@ -1048,7 +877,6 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
         }
       }
     }
-    MIRTJ_STAMP(1);  // classification + parse
     // ---- request the next group's stream bytes and the block offset of the group after it: they arrive while
     // this group is transformed ----
     typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -1067,7 +895,7 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
       // fetched here they would occupy nine registers across the transform on every path; the hand-issued loads
       // below then read this packet's descriptor (64 valid bytes) instead
       if (!inside_n) {
-        g4b = (const uint8_t*)(frames + blockIdx.y);
+        g4b = (const uint8_t*)uniform_ptr(frames + fidx);
         g4o = 0u;
       }
       // one block, issued on every path that has a next group: its results take part in no selection before the
@@ -1080,7 +908,7 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
           "global_load_dwordx4 %0, %4, %5\n\t"
           "global_load_dwordx4 %1, %4, %5 offset:16\n\t"
           "global_load_dword %2, %4, %5 offset:32\n\t"
-          "global_load_dword %3, %6, %7"
+          "global_load_dword %3, %6, %7 ; mirtj luma loads"
           : "=&v"(nb0), "=&v"(nb1), "=&v"(nb2), "=&v"(pos_nn)
           : "v"(g4o), "s"(g4b), "v"(offp), "s"(off)
           : "memory");
@@ -1088,7 +916,7 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
 
     // ---- does any block of the wave reach outside the low 4x4?  (columns 4-7, rows 4-7) ----
     bool lo = false;
-    const bool try_lo = (chroma ? try_lo_c : try_lo_y) && !pool_it;  // (a pooling round transforms nothing)
+    const bool try_lo = chroma ? try_lo_c : try_lo_y;
     if (try_lo) {  // wave-uniform
       uint32_t hi = 0;
       if (live_blk) {
@@ -1100,14 +928,10 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
         }
       }
       lo = !__any(hi != 0u);
-#ifdef MIRTJ_EXP_FIXED_PATHS  // timing experiments on wrong data: the paths the bench content takes, whatever the scratch holds
-      lo = chroma;
-#endif
       if (chroma) try_lo_c = lo;
       else try_lo_y = lo;
     }
 
-    MIRTJ_STAMP(2);  // look-ahead loads issued, low-4x4 test
     if (live_blk) {
       const uint32_t off32 = block_offset(grp, dmb, kblk, mb);
       uint8_t* plane = outbuf + plane_off;  // wave-uniform; steps from row to row on the scalar side
@@ -1123,7 +947,6 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
       };
       const IdctK K{362, 473, -669, 277, 128, 235};
       const IdctPK KP = idct_pk_constants();
-      auto half16 = [](uint32_t w, int odd) -> int { return odd ? (int)w >> 16 : (int)(int16_t)(w & 0xFFFFu); };
       auto put_row = [&](const int (&y)[8]) {
         uint2 o;
         // three shift-or instructions per four pixels, spelled out: the compiler's own choice for
@@ -1133,13 +956,8 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
         put_packed(o);
       };
 
-#ifdef MIRTJ_EXP_NO_TRANSFORM
-      if (true) {
-        for (int r = 0; r < kRowStores; r++) put_packed(make_uint2(0u, 0u));
-      } else
-#endif
       if (lo) {
-        lo_forms(put_packed);
+        transform_lo(my, K, KP, put_packed);
       } else {
         bool packed = false;
 #if MIRTJ_PK_IDCT
@@ -1147,11 +965,6 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
 #pragma unroll
         for (int i = 0; i < 8; i++) q[i] = my[i];
         packed = __all(pk_range_full(q, KP));  // wave-uniform
-#ifdef MIRTJ_EXP_PK_ONLY
-        packed = true;  // census builds have no other path: a wave that stored nothing would break the counted wait below
-                        // (profiles/r03/faults/: exactly that happened with an unparsed scratch)
-#endif
-        MIRTJ_STAMP(5);  // coordinates, scratch reads, 16-bit range test
         if (packed) {
           // ---- column pass on the four column pairs, as they lie in the scratch (rtj_idct_pk.h) ----
           uint32_t yy[4][8];
@@ -1176,8 +989,8 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
           }
         }
 #endif
-#ifndef MIRTJ_EXP_PK_ONLY
-        if (!packed) {
+        if (kList && !packed) rows_stored = false;  // not this kernel's business: the whole part goes to k_decode_list
+        if (!kList && !packed) {
           // ---- column pass: column c is one half of the 16-byte pieces c & ~1 (rows 0-3) and (c & ~1) + 1 (rows 4-7) ----
           // Two rounds, rows 0-3 and rows 4-7, each with a column pass of its own: this path is the rare one (a block
           // outside the 16-bit budget), and 32 + 32 registers of column results are what the kernel's register count —
@@ -1231,15 +1044,15 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
           }
 #endif
         }
-#endif  // MIRTJ_EXP_PK_ONLY
       }
     }
-    MIRTJ_STAMP(3);  // coordinates, transform, row stores
+    // (appended behind the counted wait, or on the way out: the append is an atomic and a store, and nothing but the row
+    // stores may sit between the hand-issued loads and their wait)
+    const bool to_list = kList && __ballot(live_blk && !rows_stored) != 0ull;  // wave-uniform
     if (!have_n) {
-      if (kPool && npool != 0u) {  // the wave's last round is done: the pool's transform round, then out
-        virt = true;
-        virt_last = true;
-        continue;
+      if (to_list) {
+        exit_grp = grp;
+        exit_part = s0.part;
       }
       break;
     }
@@ -1247,20 +1060,20 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
     // operations" is exactly "everything requested before the transform" — unless no lane had a live block: such a wave
     // stored nothing and waits for all there is.  (kRowStores sits next to the stores it counts: put_packed above.)
     {
-      const uint32_t younger = __ballot(live_blk) != 0ull ? (uint32_t)kRowStores : 0u;  // (a pooling round stores nothing)
+      const uint32_t younger = __ballot(live_blk && rows_stored) != 0ull ? (uint32_t)kRowStores : 0u;
       asm volatile(
           "s_cmp_eq_u32 %4, 8\n\t"
           "s_cbranch_scc1 .Lmirtj_w8_%=\n\t"
           "s_waitcnt vmcnt(0)\n\t"
           "s_branch .Lmirtj_arrived_%=\n"
           ".Lmirtj_w8_%=:\n\t"
-          "s_waitcnt vmcnt(8)\n"
+          "s_waitcnt vmcnt(8) ; mirtj luma wait\n"
           ".Lmirtj_arrived_%=:"
           : "+v"(nb0), "+v"(nb1), "+v"(nb2), "+v"(pos_nn)
           : "s"(younger)
           : "scc", "memory");
     }
-    MIRTJ_STAMP(4);  // the counted wait for the look-ahead loads
+    if (to_list) declist_push(list, fidx, grp, s0.part);
     pos0 = pos_n;
     // a copy of our own, BEHIND the wait: left to the compiler, the loop-carried register of pos_n may be filled by a
     // copy it places in front of the wait block (tools/check_async_loads.py found exactly that)
@@ -1274,19 +1087,8 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
     }
     inside = inside_n;
     it++;
-    // the pool's transform round runs next when the pooled rounds' registers are used up or another round's general
-    // blocks might not fit in (a round that does not fit is a plain round, see above)
-    if (kPool && (npool == kPoolSlots || pool_g >= kPoolFlushFrom)) virt = true;
   }
-#ifdef MIRTJ_STAMPS
-  if (lane == 0) {
-    for (int i = 0; i < 7; i++) {
-      atomicAdd(&g_stamps[i], st_y[i]);
-      atomicAdd(&g_stamps[8 + i], st_c[i]);
-    }
-    atomicAdd(&g_stamps[7], 1ull);
-  }
-#endif
+  if (kList && exit_grp != ~0u) declist_push(list, fidx, exit_grp, exit_part);
 }
 
 // k_decode<kRot, kPrev>: see above.  kRot: grid (slots, frames), a wave takes all three parts of its groups; else grid
@@ -1300,7 +1102,10 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
                                                          uint8_t* __restrict__ outbuf,
                                                          const uint8_t* __restrict__ prev) {
   __shared__ __attribute__((aligned(16))) uint32_t s_lds[kDecLdsWords];
-  decode_wave<kRot, kPrev>(s_lds, frames, stream, lut, blkoff, outbuf, prev);
+  const uint32_t slots = kRot ? gridDim.x : gridDim.x / 3u;
+  const uint32_t slot = kRot ? blockIdx.x : blockIdx.x / 3u, part0 = kRot ? 0u : blockIdx.x - slot * 3u;
+  decode_wave<kRot, kPrev, 3, false>(s_lds, frames, blockIdx.y, slot, slots, part0, stream, lut, blkoff, outbuf, prev,
+                                     DecList{nullptr, nullptr, 0u});
 }
 
 }  // namespace mirtj

@@ -79,6 +79,30 @@ __host__ __device__ constexpr size_t spec_bits_words(uint64_t walkers) {  // dwo
 __host__ __device__ constexpr size_t spec_bits_dword(uint32_t walker, uint32_t k) {
   return (((size_t)(walker >> 6) * (size_t)kSpecTilesMax + (k >> 2)) * 64u + (walker & 63u)) * 4u + (k & 3u);
 }
+// The layout's bounds, checked where the layout is defined: every (walker, dword) of a
+// launch of `walkers` walkers — the idle lanes of the last wave stand in for the spare walker `walkers` — lies inside
+// spec_bits_words(walkers), and no two of them share a dword.  Evaluated at compile time for walker counts on both
+// sides of a wave boundary; a change of either function that breaks this does not build.
+constexpr bool spec_bits_layout_ok(uint32_t walkers) {
+  const size_t words = spec_bits_words(walkers);
+  const uint32_t rows = ((walkers + 1u + 63u) / 64u) * 64u;  // walker rows the kernels may touch (whole waves)
+  size_t top = 0;
+  for (uint32_t w = 0; w < rows; w++)
+    for (uint32_t k = 0; k < (uint32_t)kSpecTilesMax * 4u; k++) {
+      const size_t d = spec_bits_dword(w, k);
+      if (d >= words) return false;
+      top = d > top ? d : top;
+    }
+  // dense: rows * dwords-per-walker distinct values below `words` with the largest at words - 1 means a bijection
+  // only if the map is injective; both layouts used so far are mixed-radix numberings, checked on the first two waves
+  for (uint32_t w = 0; w < (rows < 128u ? rows : 128u); w++)
+    for (uint32_t k = 0; k < (uint32_t)kSpecTilesMax * 4u; k++)
+      if (w + 1u < rows && spec_bits_dword(w, k) == spec_bits_dword(w + 1u, k)) return false;
+  return top + 1u == (size_t)rows * (size_t)kSpecTilesMax * 4u && top + 1u <= words;
+}
+static_assert(spec_bits_layout_ok(1) && spec_bits_layout_ok(63) && spec_bits_layout_ok(64) && spec_bits_layout_ok(65) &&
+                  spec_bits_layout_ok(200),
+              "a walker's start bits leave the buffer");
 constexpr uint64_t kSpecMinWalkers = 40000;  // below this (~100 MB of packets) the exact kernels index a batch faster:
                                             // a walker is one lane and runs ~0.35 ms whatever the batch (host policy)
 constexpr int kSpecRingRow = 64 + 16;       // LDS bytes per lane: the start bits of the last four tiles (512 bytes of

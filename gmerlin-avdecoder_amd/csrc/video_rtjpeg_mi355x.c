@@ -21,7 +21,7 @@
  *
  * Options (the stream's options dictionary first, s->opt as lib/video_v4l2_m2m.c:66 reads BGAV_OPT_VIDEOBUFFER from it;
  * the environment as fallback): "mi355x-device" / MI_RTJ_DEVICE = HIP device ordinal, "mi355x-depth" / MI_RTJ_DEPTH =
- * packets in flight (2..64, default 6).
+ * packets in flight (2..64, default 12).
  */
 #include <stdlib.h>
 #include <string.h>
@@ -169,8 +169,12 @@ static gavl_source_status_t fill_pipeline(bgav_stream_t *s) {
     }
     priv->meta[priv->next_tag % MI_RTJ_MAX_DEPTH] = *p;
     priv->meta[priv->next_tag % MI_RTJ_MAX_DEPTH].buf.buf = NULL; /* the bytes are not ours to keep */
-    /* time stamps that jump forward: somebody skipped packets at the source (see decode_rtjpeg_pipe) */
-    if (priv->have_last && p->duration > 0 && p->pts > priv->last_end) {
+    /* time stamps that jump forward: somebody MAY have skipped packets at the source (see decode_rtjpeg_pipe).  Only
+     * armed for a stream without compression info: with one, init marked the stream GAVL_COMPRESSION_HAS_P_FRAMES and
+     * bgav_video_skipto never skips at the source (lib/video.c:612-634 calls .skipto instead), so a forward jump is a
+     * property of the stream — an empty edit, dropped-frame chunks, a fragment gap — and every picture is shown, as
+     * lib/video_rtjpeg.c shows one picture per packet. */
+    if (!s->ci && priv->have_last && p->duration > 0 && p->pts > priv->last_end) {
       priv->gap_tag = priv->next_tag;
       priv->have_gap = 1;
     }
@@ -201,7 +205,8 @@ static gavl_source_status_t decode_rtjpeg_pipe(bgav_stream_t *s, gavl_video_fram
     /* Should the library skip packets at the source all the same (its intra-only branch; init asks it not to), what
      * is in flight ends before the skip's target and is stale.  Two things prove that packets were skipped behind us:
      * s->out_time (set to the first packet kept, lib/video.c:607) lies past the end of the last packet read here — then
-     * everything in flight goes —, or the time stamps of the packets read jump — then everything before the jump goes.
+     * everything in flight goes —, or, for a stream without compression info (the only kind the library can still skip
+     * packets of at the source), the time stamps of the packets read jump — then everything before the jump goes.
      * Without either nothing was skipped at the source and nothing is dropped: round 2's rule (drop what ends before
      * s->out_time) threw away pictures the caller was still waiting for when the target lay inside the read-ahead
      * window, where out_time is just the start of the next unread packet. */

@@ -20,6 +20,9 @@
  *                 application playing K files would (doc/mainpage.incl:54-55: instances may run on different threads);
  *                 the figure printed is the aggregate
  *   opt=KEY:INT   an entry of the stream's options dictionary (s->opt), e.g. opt=mi355x-depth:3
+ *   ptsjump=N:D   packets N.. carry time stamps D later: a forward jump that is a property of the stream (an empty
+ *                 edit, a fragment gap), nothing is skipped
+ *   noci=1        the stream has no compression info (s->ci == NULL)
  *
  * skipto= follows the library: streams whose compression info says GAVL_COMPRESSION_HAS_P_FRAMES go to the decoder's
  * .skipto (or decode-and-drop), the others have their packets skipped at the source; skippkts= forces the latter.
@@ -127,7 +130,7 @@ static int load_mov(const char *path, queue_t *q, uint32_t *fourcc, int *w, int 
 /* what one stream is asked to do, and what came of it */
 typedef struct {
   const gavl_packet_t *pkts;
-  int n, repeat, iw, ih, skip_every, seek_at, seek_to, skipto_at, skippkts_at, bench, warm;
+  int n, repeat, iw, ih, skip_every, seek_at, seek_to, skipto_at, skippkts_at, bench, warm, noci;
   long long skipto_t, skippkts_t;
   uint32_t fourcc;
   const gavl_dictionary_t *opt;
@@ -158,7 +161,7 @@ static void *play(void *arg) {
   s.m = &meta;
   s.info = &info;
   s.opt = c->opt;
-  s.ci = &ci;
+  s.ci = c->noci ? NULL : &ci;
   s.data.video.format = &fmt;
   s.harness = &q;
 
@@ -260,7 +263,8 @@ static void *play(void *arg) {
 int main(int argc, char **argv) {
   if (argc < 5) return fprintf(stderr, "usage: %s packets.bin|movie.mov w h out.bin [skip_every]  (w h 0 0: from the movie)\n", argv[0]), 1;
   int iw = atoi(argv[2]), ih = atoi(argv[3]);
-  int streams = 1;
+  int streams = 1, jump_at = -1;
+  long long jump_by = 0;
   play_t cfg = {0};
   gavl_dictionary_t opt;
   memset(&opt, 0, sizeof opt);
@@ -277,6 +281,8 @@ int main(int argc, char **argv) {
     if (sscanf(argv[i], "bench=%d", &cfg.bench) == 1) continue;
     if (sscanf(argv[i], "warm=%d", &cfg.warm) == 1) continue;
     if (sscanf(argv[i], "streams=%d", &streams) == 1) continue;
+    if (sscanf(argv[i], "ptsjump=%d:%lld", &jump_at, &jump_by) == 2) continue;
+    if (sscanf(argv[i], "noci=%d", &cfg.noci) == 1) continue;
     if (sscanf(argv[i], "opt=%31[^:]:%d", key, &val) == 2 && opt.n_ints < MI_COMPAT_DICT_INTS) {
       snprintf(opt.ints[opt.n_ints].key, sizeof opt.ints[0].key, "%s", key);
       opt.ints[opt.n_ints++].val = val;
@@ -308,6 +314,8 @@ int main(int argc, char **argv) {
     }
     fclose(fi);
   }
+  for (int i = 0; i < q.n; i++)
+    if (jump_at >= 0 && i >= jump_at) q.pkts[i].pts += jump_by;
   if (streams < 1 || streams > 16 || (streams > 1 && !cfg.bench)) return fprintf(stderr, "streams=1..16, more than one only with bench=1\n"), 1;
 
   /* bgav_codecs_init -> bgav_init_video_decoders_rtjpeg (lib/codecs.c:176) */

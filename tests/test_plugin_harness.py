@@ -264,6 +264,40 @@ def test_source_side_skip_without_a_jump_in_time_stamps_drops_nothing(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("depth", [4, 12])
+def test_a_forward_jump_in_the_time_stamps_loses_no_picture(tmp_path, depth):
+    """time stamps that jump forward without anybody skipping packets (an empty edit, dropped-frame chunks, a
+    fragment gap) are a property of the stream: one picture per packet comes out, as from lib/video_rtjpeg.c.  (The
+    decoder marks its stream GAVL_COMPRESSION_HAS_P_FRAMES, so the library never skips packets at the source.)"""
+    build_harness()
+    w, h = 320, 240
+    enc = R.OracleEncoder(w, h, 200)
+    pkts = [enc.encode(R.synth_frame(w, h, i, seed=12, amp=10)) for i in range(20)]
+    r, recs = run_pipe(tmp_path, pkts, w, h, "ptsjump=7:1000", depth=depth)
+    assert r.returncode == 0, r.stderr
+    want = expected_stream(pkts, w, h, w, h, 0)
+    assert len(recs) == 20
+    assert [pts for _, pts in recs] == [want[i][1] + (1000 if i >= 7 else 0) for i in range(20)]
+    for (got, _), (planes, _) in zip(recs, want):
+        assert np.array_equal(got, planes)
+
+
+@pytest.mark.gpu
+def test_a_stream_without_compression_info_drops_what_a_source_side_skip_made_stale(tmp_path):
+    """without s->ci the decoder cannot ask the library for .skipto, packets may be skipped at the source, and then a
+    jump in the time stamps of the packets read is the proof: what was in flight before it is not shown"""
+    build_harness()
+    w, h = 320, 240
+    enc = R.OracleEncoder(w, h, 200)
+    pkts = [enc.encode(R.synth_frame(w, h, i, seed=13, amp=10)) for i in range(20)]
+    r, recs = run_pipe(tmp_path, pkts, w, h, f"skippkts=3:{1000 + 40 * 12 + 1}", "noci=1", depth=6)
+    assert r.returncode == 0, r.stderr
+    want = expected_stream(pkts, w, h, w, h, 0)
+    order = list(range(3)) + list(range(12, 20))
+    assert [pts for _, pts in recs] == [want[i][1] for i in order]
+
+
+@pytest.mark.gpu
 def test_option_keys_come_before_the_environment(tmp_path):
     """device and depth are read from the stream's options dictionary (s->opt, as lib/video_v4l2_m2m.c:66 reads
     BGAV_OPT_VIDEOBUFFER), the environment is the fallback: a device that does not exist fails init whatever

@@ -40,18 +40,36 @@ def kernels_of(path, stem="k_decode"):
     return lines, out
 
 
-def check_all(path, stem="k_decode"):
-    lines, ks = kernels_of(path, stem)
-    if not ks:
-        return [f"{stem}: not found in {path}"]
+# the two hand-issued load / wait pairs of the decode kernels, told apart by the comments their asm blocks carry:
+# decode_wave's group loop (rtj_decode_kernels.h) and the pooling chroma waves' round loop (rtj_decode_chroma.h)
+ROLES = {
+    "luma": dict(loads="mirtj luma loads", wait="mirtj luma wait", arms=(0, 8), per_block=8),
+    "chroma": dict(loads="mirtj chroma pool loads", wait="mirtj chroma pool wait", arms=(0, 8, 16, 24), per_block=8),
+}
+# which pairs a kernel must hold
+KERNEL_ROLES = (("k_decode_split", ("luma", "chroma")), ("k_decode_list", ("luma",)), ("k_decode", ("luma",)))
+
+
+def check_all(path, stem=None):
     errs = []
-    for name, a, b in ks:
-        errs += check(lines[a:b], name)
+    seen = set()
+    for kstem, roles in KERNEL_ROLES:
+        if stem and stem != kstem:
+            continue
+        lines, ks = kernels_of(path, kstem)
+        ks = [k for k in ks if k[0] not in seen]
+        if not ks:
+            errs.append(f"{kstem}: not found in {path}")
+        for name, a, b in ks:
+            seen.add(name)
+            for r in roles:
+                errs += check(lines[a:b], name, r)
     return errs
 
 
-def check(body, kernel):
-    # the hand-issued block: the ASMSTART region that holds global_load_dwordx4 (exactly one, inside the group loop)
+def check(body, kernel, role="luma"):
+    R = ROLES[role]
+    # the hand-issued block: the ASMSTART region that carries the role's comment (exactly one, inside the loop)
     blocks = []
     i = 0
     while i < len(body):
@@ -59,12 +77,12 @@ def check(body, kernel):
             j = i
             while "#ASMEND" not in body[j]:
                 j += 1
-            if any("global_load_dwordx4" in t for t in body[i:j]):
+            if any(R["loads"] in t for t in body[i:j]):
                 blocks.append((i, j))
             i = j
         i += 1
     if len(blocks) != 1:
-        return [f"{kernel}: expected one hand-issued load block, found {len(blocks)}"]
+        return [f"{kernel}: expected one hand-issued {role} load block, found {len(blocks)}"]
     b0, b1 = blocks[0]
     # the loads take their bases from scalar registers: a vector instruction just in front of the block may have
     # written one (v_readlane_b32 reloading a spilled value), and nobody pads that hazard inside an asm block
@@ -86,11 +104,10 @@ def check(body, kernel):
             while "#ASMEND" not in body[j]:
                 j += 1
             txt = body[k:j]
-            if any("s_waitcnt vmcnt(8)" in x for x in txt):
-                if not any("s_waitcnt vmcnt(0)" in x for x in txt):
-                    errs.append(f"line {k}: the wait block has no vmcnt(0) arm for waves that stored nothing")
-                if any(re.search(r"vmcnt\((?!0\)|8\))", x) for x in txt):
-                    errs.append(f"line {k}: the wait block has an arm other than vmcnt(8) / vmcnt(0)")
+            if any(R["wait"] in x for x in txt):
+                arms = sorted(int(m) for x in txt for m in re.findall(r"s_waitcnt vmcnt\((\d+)\)", x))
+                if tuple(arms) != R["arms"]:
+                    errs.append(f"line {k}: the {role} wait block has the arms vmcnt{arms}, expected {R['arms']}")
                 wait_at = k
                 break
     if wait_at is None:
@@ -142,7 +159,7 @@ def check(body, kernel):
     # block holds more than a variant's eight.  That each executed path issues the 8 stores the counted wait
     # assumes is what the parity tests show at run time: a wait that is one short hands the parser stale registers.
     per_block = [b["stores"] for b in blocks_]
-    if max(per_block) > 8 or sum(per_block) < 8:
+    if max(per_block) > R["per_block"] or sum(per_block) < 8:
         errs.append(f"{kernel}: stores per basic block {sorted(n for n in per_block if n)}")
     for k in range(b1 + 1, wait_at):
         t = body[k].split(";")[0].strip()
@@ -152,7 +169,7 @@ def check(body, kernel):
 
 
 if __name__ == "__main__":
-    e = check_all(sys.argv[1], "k_decode")
+    e = check_all(sys.argv[1])
     for x in e:
         print("ASYNC-LOAD CHECK:", x)
     print("pending-load check:", "clean" if not e else f"{len(e)} problem(s)")
