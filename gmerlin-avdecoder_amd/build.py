@@ -64,6 +64,27 @@ def build(force=False, verbose=False, out=None):
     return out or LIB
 
 
+DV_LIB = os.path.join(LIBDIR, "libmi_dv.so")
+DV_SOURCES = ["mi_dv.hip", "dv_tables.cpp"]
+
+
+def build_dv(force=False, verbose=False):
+    """libmi_dv.so: the DV25 525/60 decoder (include/mi_dv.h), gfx950."""
+    deps = [os.path.join(CSRC, f) for f in DV_SOURCES + ["dv_common.h", "dv_decode_kernels.h"]] + \
+           [os.path.join(HERE, "..", "include", "mi_dv.h")]
+    if not force and os.path.exists(DV_LIB) and all(os.path.getmtime(f) <= os.path.getmtime(DV_LIB) for f in deps):
+        return DV_LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"] + \
+        os.environ.get("MI_DV_CFLAGS", "").split() + ["-o", DV_LIB] + [os.path.join(CSRC, s) for s in DV_SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    return DV_LIB
+
+
 TEST_VARIANT = os.path.join(LIBDIR, "libmi_rtjpeg_generic_paths.so")
 
 
@@ -85,5 +106,28 @@ def build_test_variant(force=False):
             os.environ["MI_RTJ_CFLAGS"] = old
 
 
+EXP_LIB = os.path.join(LIBDIR, "libmi_rtjpeg_exp.so")
+
+
+def build_experiments(force=False):
+    """The same library with -DMIRTJ_EXPERIMENTS: the measurement switches that leave work out or run forms that were
+    measured slower (exp_env() in mi_rtjpeg.hip) exist in this build only.  For tools/ (MI_RTJ_LIB=...), never shipped
+    as the product and not built by __graft_entry__.build()."""
+    if not force and os.path.exists(EXP_LIB) and all(os.path.getmtime(f) <= os.path.getmtime(EXP_LIB) for f in _deps()):
+        return EXP_LIB
+    old = os.environ.get("MI_RTJ_CFLAGS")
+    os.environ["MI_RTJ_CFLAGS"] = ((old + " ") if old else "") + "-DMIRTJ_EXPERIMENTS"
+    try:
+        return build(force=True, out=EXP_LIB)
+    finally:
+        if old is None:
+            del os.environ["MI_RTJ_CFLAGS"]
+        else:
+            os.environ["MI_RTJ_CFLAGS"] = old
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_dv(force="--force" in sys.argv, verbose=True))
+    if "--experiments" in sys.argv:
+        print(build_experiments(force=True))

@@ -1,0 +1,341 @@
+// dv_decode_kernels.h — gfx950 kernel of the DV25 525/60 video decoder (the arithmetic: DESIGN.md section 9; the
+// format: IEC 61834-2 / SMPTE 314M; nothing in the reference to follow — lib/dvframe.c:663-676 passes the DIF frame on).
+//
+//   k_dv_decode    one wave per two video segments (2 x 5 compressed macroblocks = 60 blocks, one lane each):
+//                  the three passes of the variable-length decode, reconstruction, both inverse transforms, placement.
+//
+// A video segment is the unit nothing crosses: its 30 blocks share their unused bits (pass 2 inside a macroblock,
+// pass 3 across the segment), and its five macroblocks land in five different super blocks of the picture.  Integer
+// only; no MFMA (variable-length decode and a rounded butterfly).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dv_common.h"
+
+namespace midv {
+
+constexpr int kLaneStride = 144;  // bytes of LDS scratch per lane: 64 int16 coefficients + padding (16-byte reads without bank conflicts)
+constexpr int kMbufWords = 20;    // a macroblock's free space: at most 6 x 100 bits, + a dword to read past
+constexpr int kVbufWords = 86;    // a segment's: at most 2680 bits, + a dword to read past
+
+__device__ __forceinline__ int dv_mul(int x, int c) { return (x * c + 128) >> 8; }
+// the scaled 8-point butterfly (lib/RTjpeg.c:2240-2283 as SURVEY.md appendix A.4 states it) and its even half
+__device__ __forceinline__ void dv_idct8(const int (&x)[8], int (&y)[8]) {
+  const int t10 = x[0] + x[4], t11 = x[0] - x[4], t13 = x[2] + x[6], t12 = dv_mul(x[2] - x[6], 362) - t13;
+  const int e0 = t10 + t13, e3 = t10 - t13, e1 = t11 + t12, e2 = t11 - t12;
+  const int z13 = x[5] + x[3], z10 = x[5] - x[3], z11 = x[1] + x[7], z12 = x[1] - x[7];
+  const int o7 = z11 + z13, m = dv_mul(z11 - z13, 362), z5 = dv_mul(z10 + z12, 473);
+  const int t10o = dv_mul(z12, 277) - z5, t12o = dv_mul(z10, -669) + z5;
+  const int o6 = t12o - o7, o5 = m - o6, o4 = t10o + o5;
+  y[0] = e0 + o7; y[7] = e0 - o7; y[1] = e1 + o6; y[6] = e1 - o6;
+  y[2] = e2 + o5; y[5] = e2 - o5; y[4] = e3 + o4; y[3] = e3 - o4;
+}
+__device__ __forceinline__ void dv_idct4(int x0, int x1, int x2, int x3, int (&a)[4]) {
+  const int t10 = x0 + x2, t11 = x0 - x2, t13 = x1 + x3, t12 = dv_mul(x1 - x3, 362) - t13;
+  a[0] = t10 + t13; a[3] = t10 - t13; a[1] = t11 + t12; a[2] = t11 - t12;
+}
+
+// 16 bits (in the top half of the result) of an LDS bit buffer from bit position bp on, MSB first
+__device__ __forceinline__ uint32_t dv_peek(const uint32_t* buf, uint32_t bp) {
+  const uint32_t i = bp >> 5, sh = bp & 31u;
+  const uint32_t d0 = buf[i], d1 = buf[i + 1];
+  return sh ? (d0 << sh) | (d1 >> (32u - sh)) : d0;
+}
+// OR `n` bits (the top n of v, n <= 32, the rest of v zero) into an LDS bit buffer at bit position bp
+__device__ __forceinline__ void dv_or_bits(uint32_t* buf, uint32_t bp, uint32_t v) {
+  const uint32_t i = bp >> 5, sh = bp & 31u;
+  atomicOr(&buf[i], v >> sh);
+  if (sh) atomicOr(&buf[i + 1], v << (32u - sh));
+}
+
+__global__ __launch_bounds__(64) void k_dv_decode(const uint8_t* __restrict__ frames, uint8_t* __restrict__ pics,
+                                                   const Tables* __restrict__ T) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_coef[64 * kLaneStride];
+  __shared__ uint32_t s_lut9[512], s_lut2[64], s_tab[128], s_sh[24];
+  __shared__ uint32_t s_mbuf[10][kMbufWords], s_vbuf[2][kVbufWords];
+  __shared__ uint32_t s_mpos[10], s_mlen[10], s_vpos[2], s_vlen[2], s_excl[64];
+
+  const int lane = threadIdx.x;
+  for (int i = lane; i < 512; i += 64) s_lut9[i] = T->lut9[i];
+  s_lut2[lane] = T->lut2[lane];
+  s_tab[lane] = T->tab[0][lane];
+  s_tab[64 + lane] = T->tab[1][lane];
+  if (lane < 24) s_sh[lane] = T->shift4[lane];
+  for (int i = lane; i < 10 * kMbufWords; i += 64) (&s_mbuf[0][0])[i] = 0u;
+  for (int i = lane; i < 2 * kVbufWords; i += 64) (&s_vbuf[0][0])[i] = 0u;
+
+  // ---- which block this lane has ----
+  const bool live = lane < 60;
+  const uint32_t seg = (uint32_t)lane / 30u, b30 = (uint32_t)lane - 30u * seg, mbi = b30 / 6u, j = b30 - 6u * mbi;
+  const uint32_t mb10 = (uint32_t)lane / 6u;  // macroblock of the wave, 0..9 (10: the idle lanes)
+  uint32_t S = 2u * blockIdx.x + seg;          // video segment of the frame
+  if (S >= (uint32_t)kSegments) S = kSegments - 1;  // (never: 270 is even)
+  const uint32_t seq = S / 27u, slot = S - 27u * seq;
+  const uint32_t v = 5u * slot + mbi;
+  const uint8_t* mbp = frames + (size_t)blockIdx.y * kFrameBytes + (size_t)((seq * 150u + 7u + v + v / 15u) * 80u);
+  const uint32_t ao = j < 4u ? 4u + 14u * j : 60u + 10u * (j - 4u);  // the block's area inside the compressed macroblock
+  const uint32_t A = j < 4u ? 112u : 80u;                            // ... and its bits
+  uint32_t W0, W1, W2, W3;  // the area's bits, MSB first, shifted left as they are consumed
+  uint32_t qno;
+  {
+    const uint32_t* p4 = (const uint32_t*)(mbp + (ao & ~3u));
+    const uint32_t d0 = p4[0], d1 = p4[1], d2 = p4[2], d3 = j == 5u ? 0u : p4[3];  // (area 5 ends with the DIF block)
+    const uint32_t sh = ao & 3u;
+    const uint32_t b0 = __builtin_amdgcn_alignbyte(d1, d0, sh), b1 = __builtin_amdgcn_alignbyte(d2, d1, sh),
+                   b2 = __builtin_amdgcn_alignbyte(d3, d2, sh), b3 = __builtin_amdgcn_alignbyte(0u, d3, sh);
+    W0 = __builtin_bswap32(b0); W1 = __builtin_bswap32(b1); W2 = __builtin_bswap32(b2); W3 = __builtin_bswap32(b3);
+    qno = ((const uint32_t*)mbp)[0] >> 24 & 15u;  // byte 3: STA | QNO
+  }
+  const int dc = (int)W0 >> 23;
+  const uint32_t mode = (W0 >> 22) & 1u, cls = (W0 >> 20) & 3u;
+  // consume n bits (1 <= n <= 31)
+  auto shift = [&](uint32_t n) {
+    const uint32_t r = 32u - n;
+    W0 = (W0 << n) | (W1 >> r);
+    W1 = (W1 << n) | (W2 >> r);
+    W2 = (W2 << n) | (W3 >> r);
+    W3 <<= n;
+  };
+  shift(12u);
+  uint32_t p = 12u;
+  uint8_t* const my = s_coef + lane * kLaneStride;
+  {
+    uint4* z = (uint4*)my;
+#pragma unroll
+    for (int i = 0; i < 8; i++) z[i] = make_uint4(0, 0, 0, 0);
+  }
+  __syncthreads();
+  *(int16_t*)my = (int16_t)(dc * 4 + 1024 + 4);  // level shift and DESCALE's rounding term ride on the DC (both passes are linear in it)
+  const uint32_t sh4 = s_sh[qno + (cls == 0u ? 6u : cls == 1u ? 3u : cls == 2u ? 0u : 1u)] + (cls == 3u ? 0x1111u : 0u);
+  const uint32_t tab_m = 64u * mode;
+
+  // a code word: its table entry from the next 16 bits (top of w)
+  auto lookup = [&](uint32_t w) -> uint32_t {
+    if ((w >> 27) != 31u) return s_lut9[w >> 23];
+    const uint32_t i7 = (w >> 20) & 127u;
+    if (i7 < 64u) return s_lut2[i7];
+    if (i7 < 96u) return vlc_entry(13u, ((w >> 19) & 63u) + 1u, 0u);  // 1111110 rrrrrr: a run of zeros (and one more)
+    return vlc_entry(16u, 1u, (w >> 17) & 255u);                       // 1111111 aaaaaaaa s
+  };
+  uint32_t pos = 0;  // scan position of the coefficient decoded last; > 63: the block is finished
+  auto apply = [&](uint32_t e, uint32_t w) {  // the word is complete: move on, store the coefficient
+    const uint32_t len = e & 31u;
+    pos += (e >> 5) & 127u;
+    if (pos > 63u) return;
+    const uint32_t amp = (e >> 12) & 255u;
+    const int level = (w >> (32u - len)) & 1u ? -(int)amp : (int)amp;
+    const uint32_t t = s_tab[tab_m + pos];
+    const uint32_t s = (sh4 >> (4u * ((t >> 8) & 3u))) & 15u;
+    *(int16_t*)(my + (t & 255u)) = (int16_t)((level * (int)((t >> 16) << s) + 8192) >> 14);
+  };
+
+  // ---- pass 1: every block from its own area ----
+  bool act = live;
+  while (__any(act)) {
+    if (act) {
+      const uint32_t e = lookup(W0), len = e & 31u;
+      if (p + len > A) {
+        act = false;  // the word does not end inside the area: its A - p bits stay in W0
+      } else {
+        apply(e, W0);
+        shift(len);
+        p += len;
+        act = pos <= 63u;
+      }
+    }
+  }
+  bool fin = pos > 63u;
+  uint32_t part = 0, npart = 0;  // an unfinished block's cut-off word: npart bits at the top of part
+  uint32_t rem = A - p;          // bits left in the area: free space of a finished block, the cut-off word of another
+  if (!live) rem = 0u;
+  if (!fin) {
+    npart = rem;
+    part = rem ? W0 & ~(0xFFFFFFFFu >> rem) : 0u;
+    rem = 0u;
+  }
+  // ---- the macroblock's free space: what its finished blocks left, in block order ----
+  {
+    uint32_t incl = rem;  // inclusive scan over the wave (60 values below 101: sums below 2^16)
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    s_excl[lane] = incl - rem;
+    __syncthreads();
+    const uint32_t base = s_excl[6u * mb10 < 64u ? 6u * mb10 : 63u];
+    const uint32_t at = incl - rem - base;  // where this block's bits go in its macroblock's buffer
+    if (live && j == 5u) {
+      s_mlen[mb10] = at + rem;
+      s_mpos[mb10] = 0u;
+    }
+    if (rem) {
+      uint32_t* mb = s_mbuf[mb10];
+      uint32_t w[4] = {W0, W1, W2, W3};
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        if (rem > 32u * i) {
+          const uint32_t n = rem - 32u * i;
+          dv_or_bits(mb, at + 32u * i, n >= 32u ? w[i] : w[i] & ~(0xFFFFFFFFu >> n));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // lanes that want bits take turns, lowest lane of a group first, reading from the group's buffer until their block
+  // is finished or the buffer is used up
+  auto drain = [&](uint32_t gmask, const uint32_t* buf, uint32_t* gpos, const uint32_t glen) {
+    for (;;) {
+      const bool want = live && !fin && *gpos < glen;
+      const unsigned long long m = __ballot(want);
+      if (m == 0ull) break;
+      const unsigned long long mine = m & gmask;
+      if (want && (uint32_t)lane == (uint32_t)__builtin_ctzll(mine)) {
+        uint32_t bp = *gpos;
+        for (;;) {
+          const uint32_t avail = glen - bp;
+          uint32_t w = dv_peek(buf, bp);
+          if (npart) w = part | (w >> npart);
+          const uint32_t e = lookup(w), len = e & 31u;
+          if (len > npart + avail) {  // cut off again: keep what there is
+            const uint32_t have = npart + avail;
+            part = have ? w & ~(0xFFFFFFFFu >> have) : 0u;
+            npart = have;
+            bp = glen;
+            break;
+          }
+          bp += len - npart;
+          npart = 0u;
+          part = 0u;
+          apply(e, w);
+          if (pos > 63u) {
+            fin = true;
+            break;
+          }
+        }
+        *gpos = bp;
+      }
+      __syncthreads();
+    }
+  };
+  // ---- pass 2: inside the macroblock ----
+  drain(0x3Full << (6u * mb10 < 60u ? 6u * mb10 : 60u), s_mbuf[mb10 < 10u ? mb10 : 9u], &s_mpos[mb10 < 10u ? mb10 : 9u],
+        live ? s_mlen[mb10] : 0u);
+  // ---- the segment's free space: what its macroblocks left (those whose blocks are all finished) ----
+  {
+    const unsigned long long unf = __ballot(live && !fin);
+    const bool allfin = (unf & (0x3Full << (6u * (mb10 < 10u ? mb10 : 0u)))) == 0ull;
+    const uint32_t left = live && j == 0u && allfin ? s_mlen[mb10] - s_mpos[mb10] : 0u;
+    s_excl[lane] = left;
+    __syncthreads();
+    if (live && j == 0u) {
+      uint32_t at = 0;
+      for (uint32_t k = 0; k < mbi; k++) at += s_excl[30u * seg + 6u * k];
+      if (mbi == 4u) {
+        s_vlen[seg] = at + left;
+        s_vpos[seg] = 0u;
+      }
+      const uint32_t* mb = s_mbuf[mb10];
+      uint32_t from = s_mpos[mb10];
+      for (uint32_t done = 0; done < left; done += 32u) {
+        const uint32_t n = left - done;
+        uint32_t w = dv_peek(mb, from + done);
+        if (n < 32u) w &= ~(0xFFFFFFFFu >> n);
+        dv_or_bits(s_vbuf[seg], at + done, w);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- pass 3: across the segment ----
+  drain(seg ? 0x3FFFFFFFull << 30 : 0x3FFFFFFFull, s_vbuf[seg < 2u ? seg : 1u], &s_vpos[seg < 2u ? seg : 1u],
+        live ? s_vlen[seg] : 0u);
+
+  // ---- inverse transform and placement ----
+  if (!live) return;
+  int c[64];
+  {
+    const uint4* q = (const uint4*)my;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const uint4 t = q[r];
+      const uint32_t d[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        c[8 * r + 2 * k] = (int)(int16_t)(d[k] & 0xFFFFu);
+        c[8 * r + 2 * k + 1] = (int)d[k] >> 16;
+      }
+    }
+  }
+  int ws[64];
+  if (mode == 0u) {
+#pragma unroll
+    for (int h = 0; h < 8; h++) {
+      int x[8], y[8];
+#pragma unroll
+      for (int r = 0; r < 8; r++) x[r] = c[8 * r + h];
+      dv_idct8(x, y);
+#pragma unroll
+      for (int r = 0; r < 8; r++) ws[8 * r + h] = y[r];
+    }
+  } else {  // 2-4-8: rows 2v / 2v + 1 hold the sum / the difference of the two fields
+#pragma unroll
+    for (int h = 0; h < 8; h++) {
+      int a[4], b[4];
+      dv_idct4(c[h], c[16 + h], c[32 + h], c[48 + h], a);
+      dv_idct4(c[8 + h], c[24 + h], c[40 + h], c[56 + h], b);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        ws[8 * (2 * i) + h] = a[i] + b[i];
+        ws[8 * (2 * i + 1) + h] = a[i] - b[i];
+      }
+    }
+  }
+  // where the block goes (525/60 4:1:1 macroblock shuffling and placement)
+  uint32_t x32, y8;
+  {
+    const uint32_t off = mbi == 0u ? 2u : mbi == 1u ? 6u : mbi == 2u ? 8u : mbi == 3u ? 0u : 4u;
+    const uint32_t start = mbi == 0u ? 9u : mbi == 1u ? 4u : mbi == 2u ? 13u : mbi == 3u ? 0u : 18u;
+    const uint32_t i = (seq + off) % 10u;
+    const uint32_t k = slot + (mbi == 1u || mbi == 2u ? 3u : 0u);
+    const uint32_t k6 = k / 6u, km = k - 6u * k6;
+    const uint32_t serp = k6 & 1u ? 5u - km : km;
+    x32 = start + k6;
+    y8 = x32 > 21u ? 2u * serp + 6u * i : serp + 6u * i;
+  }
+  uint8_t* pic = pics + (size_t)blockIdx.y * kPicBytes;
+  typedef uint32_t u32x2a __attribute__((ext_vector_type(2), aligned(4)));
+  const bool edge = x32 == 22u;
+  uint32_t stride, org;
+  if (j < 4u) {
+    stride = kW;
+    org = edge ? (8u * y8 + 8u * (j >> 1)) * kW + 32u * x32 + 8u * (j & 1u) : 8u * y8 * kW + 32u * x32 + 8u * j;
+  } else {
+    stride = kCW;
+    org = kW * kH + (j == 4u ? kCW * kH : 0u) + 8u * y8 * kCW + 8u * x32;  // block 4 is Cr (third plane), block 5 Cb
+  }
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    int y[8];
+    const int(&xr)[8] = *(const int(*)[8])(ws + 8 * r);
+    dv_idct8(xr, y);
+    uint32_t px[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      int s = (int)((uint32_t)y[k] << 13) >> 16;  // (int16)(v >> 3): DESCALE with int16 narrowing (the + 4 came in with DC)
+      s = s < 0 ? 0 : s > 255 ? 255 : s;
+      px[k] = (uint32_t)s;
+    }
+    const uint32_t lo = px[0] | px[1] << 8 | px[2] << 16 | px[3] << 24, hi = px[4] | px[5] << 8 | px[6] << 16 | px[7] << 24;
+    if (j >= 4u && edge) {  // the right-edge chroma block: left half here, right half eight lines below
+      *(uint32_t*)(pic + org + (uint32_t)r * stride) = lo;
+      *(uint32_t*)(pic + org + (uint32_t)(r + 8) * stride) = hi;
+    } else {
+      u32x2a o;
+      o.x = lo;
+      o.y = hi;
+      *(u32x2a*)(pic + org + (uint32_t)r * stride) = o;
+    }
+  }
+}
+
+}  // namespace midv

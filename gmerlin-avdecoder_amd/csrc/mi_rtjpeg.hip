@@ -59,6 +59,11 @@ struct mi_rtj_ctx {
   uint8_t* h_frame = nullptr;     // pinned host picture of the nocopy path
   size_t h_frame_cap = 0;
   mi_rtj_plan* single = nullptr;  // reusable 1-frame plan
+  // Asynchronous producers on the instance's stream (mi_rtj_dev_memset) may have written what a plan's index kernels
+  // read on their own stream: the next launch of a plan with an index stream makes that stream wait for this event once
+  // (not at every launch — that would put the index of launch k + 1 behind the transform of launch k)
+  bool input_dirty = false;
+  hipEvent_t e_input = nullptr;
 };
 
 struct mi_rtj_plan {
@@ -208,6 +213,19 @@ struct mi_rtj_pipe {
 };
 
 namespace {
+
+// Environment switches.  Tuning knobs of the product (launch sizes, group sizes, which index runs) are read with
+// getenv; switches that only exist to take measurements — the ones that leave work out (wrong or no pictures) and the
+// A/B forms that were measured slower and are kept for the record — are read through exp_env(), which a product build
+// compiles to "not set": they exist in builds with -DMIRTJ_EXPERIMENTS only (tools/ builds those next to the product).
+inline const char* exp_env(const char* name) {
+#ifdef MIRTJ_EXPERIMENTS
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 
 int fail(mi_rtj_ctx* c, int code, const char* fmt, ...) {
   char buf[512];
@@ -416,6 +434,12 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out, int what = kL
   // picture the unchanged blocks of i + 1 come from — is still being transformed.
   hipStream_t const ds = c->stream, is = p->idx_stream ? p->idx_stream : c->stream;
   hipStream_t cur = is;
+  if (is != ds && c->input_dirty) {  // something queued on the instance's stream may still be writing the packets
+    if (!c->e_input) HIPCHK(c, hipEventCreateWithFlags(&c->e_input, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->e_input, ds));
+    HIPCHK(c, hipStreamWaitEvent(is, c->e_input, 0));
+  }
+  c->input_dirty = false;
   uint32_t* const blk = p->overlap && p->flip ? p->d_blkoff_b : p->d_blkoff;  // the index this launch writes and reads
   if (p->overlap) {
     // the launch before last read this index: its k_decode must be through with it
@@ -577,14 +601,13 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out, int what = kL
       }
       const DecList list{p->d_declist_cnt + p->declist_flip, p->d_declist, (uint32_t)p->declist_cap};
       const uint32_t slots_c = chroma_pool_slots(p->max_groups);
-#ifdef MIRTJ_EXPERIMENTS  // timing builds only (wrong pictures): MI_RTJ_SPLIT_ONLY = 1 the luma waves alone, 2 the chroma waves alone
-      if (const char* only = getenv("MI_RTJ_SPLIT_ONLY")) {
+      // (timing builds only, wrong pictures: MI_RTJ_SPLIT_ONLY = 1 the luma waves alone, 2 the chroma waves alone)
+      if (const char* only = exp_env("MI_RTJ_SPLIT_ONLY")) {
         if (atoi(only) == 1)
           hipLaunchKernelGGL(k_decode_split, dim3(dslots, drows), block, 0, ds, dfr, st, c->d_lut, blk, out8, dslots, list);
         else
           hipLaunchKernelGGL(k_decode_split, dim3(slots_c, drows), block, 0, ds, dfr, st, c->d_lut, blk, out8, 0u, list);
       } else
-#endif
       hipLaunchKernelGGL(k_decode_split, dim3(dslots + slots_c, drows), block, 0, ds, dfr, st, c->d_lut, blk, out8,
                          dslots, list);
       hipLaunchKernelGGL(k_decode_list, dim3(kDecListGrid), block, 0, ds, dfr, st, c->d_lut, blk, out8, list,
@@ -693,6 +716,7 @@ void mi_rtj_destroy(mi_rtj_ctx* c) {
   if (c->d_pkt) (void)hipFree(c->d_pkt);
   if (c->h_frame) (void)hipHostFree(c->h_frame);
   if (c->d_lut) (void)hipFree(c->d_lut);
+  if (c->e_input) (void)hipEventDestroy(c->e_input);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -753,6 +777,7 @@ int mi_rtj_dev_memset(mi_rtj_ctx* c, void* d, int v, size_t n) {
   if (!c || (!d && n)) return fail(c, MI_RTJ_ERR_ARG, "mi_rtj_dev_memset: NULL argument");
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemsetAsync(d, v, n, c->stream));
+  c->input_dirty = true;  // (plans whose index kernels run on another stream wait for it: plan_launch)
   return MI_RTJ_OK;
 }
 
@@ -982,17 +1007,6 @@ int mi_rtj_plan_spec_stats(mi_rtj_plan* p, int* proven, long long* walkers, long
   return MI_RTJ_OK;
 }
 
-#ifdef MIRTJ_STAMPS
-// diagnostic builds only (not declared in include/mi_rtjpeg.h): cycles per k_decode section since the last call
-extern "C" int mi_rtj_debug_stamps(unsigned long long out[16]) {
-  if (hipDeviceSynchronize() != hipSuccess) return MI_RTJ_ERR_HIP;
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return MI_RTJ_ERR_HIP;
-  unsigned long long zero[16] = {};
-  if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zero, sizeof zero) != hipSuccess) return MI_RTJ_ERR_HIP;
-  return MI_RTJ_OK;
-}
-#endif
-
 int mi_rtj_plan_read_index(mi_rtj_plan* p, uint32_t* dst, size_t max_entries) {
   if (!p || !dst) return MI_RTJ_ERR_ARG;
   mi_rtj_ctx* c = p->ctx;
@@ -1140,7 +1154,7 @@ inline double host_now() {
 // the caller's when the session runs without one)
 // how the pinned host pictures are allocated (MI_RTJ_HOST_FLAGS, experiments: 1 non-coherent, 2 coherent, 4 write-combined)
 unsigned pic_host_flags() {
-  const char* f = getenv("MI_RTJ_HOST_FLAGS");
+  const char* f = exp_env("MI_RTJ_HOST_FLAGS");
   const int v = f ? atoi(f) : 0;
   unsigned fl = hipHostMallocDefault;
   if (v & 1) fl |= hipHostMallocNonCoherent;
@@ -1349,15 +1363,15 @@ mi_rtj_pipe* mi_rtj_pipe_create(mi_rtj_ctx* c, int depth, int max_w, int max_h) 
   q->max_h = max_h;
   q->slot.resize(depth);
   {
-    const char* os = getenv("MI_RTJ_OUT_STREAMS");
+    const char* os = exp_env("MI_RTJ_OUT_STREAMS");
     q->n_out = os && atoi(os) == 1 ? 1 : 2;
-    const char* ok_ = getenv("MI_RTJ_OUT_KERNEL");
+    const char* ok_ = exp_env("MI_RTJ_OUT_KERNEL");
     q->out_kernel = ok_ ? atoi(ok_) : 0;  // the value is the copy kernel's grid (workgroups of 256)
-    const char* sk = getenv("MI_RTJ_EXP_SKIP");
+    const char* sk = exp_env("MI_RTJ_EXP_SKIP");
     q->exp_skip = sk ? atoi(sk) : 0;
     const char* ps = getenv("MI_RTJ_PIPE_STATS");
     q->stats = ps && atoi(ps) != 0;
-    const char* wm = getenv("MI_RTJ_WAIT");
+    const char* wm = exp_env("MI_RTJ_WAIT");
     q->wait_mode = wm && strcmp(wm, "query") == 0 ? 1 : 0;
   }
   {
@@ -1367,7 +1381,7 @@ mi_rtj_pipe* mi_rtj_pipe_create(mi_rtj_ctx* c, int depth, int max_w, int max_h) 
     // 4.39 K); with two groups of four the copy engine idles while the caller refills one (9.9 K)
     const int g = og ? atoi(og) : depth >= 12 ? 4 : 2;
     // (groups need every picture to have the session's size, and the caller's thread to be the one that queues copies)
-    const char* th0 = getenv("MI_RTJ_PIPE_THREAD");
+    const char* th0 = exp_env("MI_RTJ_PIPE_THREAD");
     q->group = (max_w > 0 && max_h > 0 && !(th0 && atoi(th0) != 0) && (g == 2 || g == 4)) ? g : 1;
     // the index is built in groups too, by default the same ones (needs the same things: one coded size, the
     // caller's thread queuing the work); MI_RTJ_IDX_GROUP = 1 is the packet-by-packet index of rounds 2 and 3
@@ -1386,7 +1400,7 @@ mi_rtj_pipe* mi_rtj_pipe_create(mi_rtj_ctx* c, int depth, int max_w, int max_h) 
     // off unless asked for: with the index on a stream of its own a 1080p session ran at 6,600 pictures per second
     // instead of 12,000 (profiles/r03/e2e_ab.txt) — every packet then crosses streams twice more, and the runtime's
     // cross-stream waits cost more than the overlap of one packet's index with its predecessor's transform gives
-    const char* ix = getenv("MI_RTJ_IDX_STREAM");
+    const char* ix = exp_env("MI_RTJ_IDX_STREAM");
     if (ix && atoi(ix) != 0) ok = ok && hipStreamCreateWithFlags(&q->s_idx, hipStreamNonBlocking) == hipSuccess;
   }
   for (int i = 0; i < q->n_out; i++) ok = ok && hipStreamCreateWithFlags(&q->s_out[i], hipStreamNonBlocking) == hipSuccess;
@@ -1446,7 +1460,7 @@ mi_rtj_pipe* mi_rtj_pipe_create(mi_rtj_ctx* c, int depth, int max_w, int max_h) 
   // caller's.  It frees the caller (which then only copies the packet into staging) but buys no throughput where it
   // was hoped to: 12,020 against 12,070 pictures per second at 1080p (the copy out bounds the session there, see
   // DESIGN.md), 20,260 against 18,870 at 320x240 (profiles/r02/e2e_worker_thread.txt).  Off by default.
-  const char* th = getenv("MI_RTJ_PIPE_THREAD");
+  const char* th = exp_env("MI_RTJ_PIPE_THREAD");
   q->threaded = th && atoi(th) != 0;
   q->jobs.assign((size_t)depth, 0);
   if (q->threaded) q->worker = std::thread(pipe_worker, q);
@@ -1618,17 +1632,22 @@ int mi_rtj_pipe_submit(mi_rtj_pipe* q, const uint8_t* pkt, size_t len, uint64_t 
   q->submitted++;
   if (!q->threaded) {
     const double ti0 = q->stats ? host_now() : 0.0;
+    bool group_failed = false;
     if (grouped) {
       sl.rc = pipe_stage(q, sl);
-      // the group's last slot: queue the kernels of the whole group.  Should that fail, the packets are in all the
-      // same; their slots carry the error and yield no pictures (mi_rtj_pipe_next reports it)
-      if (sl.rc == MI_RTJ_OK && idx % q->igroup == q->igroup - 1) (void)pipe_issue_staged(q);
+      // the group's last slot: queue the kernels of the whole group.  Should THAT fail, the group's packets are in all
+      // the same, this one included: their slots carry the error and yield no pictures, mi_rtj_pipe_next reports it once
+      // per packet, and submit returns OK — one behaviour for all members of the group (the last member used
+      // to be taken out again and reported twice while its siblings stayed in flight)
+      if (sl.rc == MI_RTJ_OK && idx % q->igroup == q->igroup - 1) group_failed = pipe_issue_staged(q) != MI_RTJ_OK;
     } else {
       sl.rc = pipe_issue(q, sl);
     }
     if (q->stats) q->t_issue += host_now() - ti0;
     sl.issued = 1;
-    if (sl.rc != MI_RTJ_OK) {  // undo: the packet never went in, its predecessor is still the last picture
+    if (group_failed) return MI_RTJ_OK;
+    if (sl.rc != MI_RTJ_OK) {  // this packet's own copy in (or, ungrouped, its kernels) could not be queued: undo — it never
+                               // went in, its predecessor is still the last picture
       q->count--;
       q->submitted--;
       q->prev_pic = was_prev;
@@ -1753,13 +1772,18 @@ int mi_rtj_pipe_flush(mi_rtj_pipe* q) {
   HIPCHK(c, hipSetDevice(c->device));
   // work in flight cannot be recalled; it is waited for and forgotten (a seek is rare, a frame takes microseconds)
   pipe_drain_jobs(q);
+  // Packets copied in whose index group was not complete yet are decoded all the same before they are forgotten:
+  // q->prev_pic — the picture of the packet submitted last — is then a picture that WAS decoded, and the first packet
+  // after the resync takes its unchanged (0xFF) blocks from it, as the reference takes them from priv->frame (ADVICE r3:
+  // they used to be dropped unindexed, and prev_pic pointed at a picture up to `depth` packets old or at zeros)
+  if (q->nstaged > 0) (void)pipe_issue_staged(q);
   HIPCHK(c, hipStreamSynchronize(q->s_in));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (q->s_idx) HIPCHK(c, hipStreamSynchronize(q->s_idx));
   for (int i = 0; i < q->n_out; i++) HIPCHK(c, hipStreamSynchronize(q->s_out[i]));
   for (auto& sl : q->slot) {
     sl.out_state = 0;
-    sl.staged = 0;  // (a packet copied in and never indexed is simply forgotten)
+    sl.staged = 0;
   }
   q->nstaged = 0;
   q->head = (q->head + q->count) % q->depth;

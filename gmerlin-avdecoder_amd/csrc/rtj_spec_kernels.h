@@ -86,19 +86,27 @@ __host__ __device__ constexpr size_t spec_bits_dword(uint32_t walker, uint32_t k
 constexpr bool spec_bits_layout_ok(uint32_t walkers) {
   const size_t words = spec_bits_words(walkers);
   const uint32_t rows = ((walkers + 1u + 63u) / 64u) * 64u;  // walker rows the kernels may touch (whole waves)
+  const uint32_t kmax = (uint32_t)kSpecTilesMax * 4u;
+  // (sampled, to stay inside the compiler's constexpr step limit: every walker row at the first and last dwords of its
+  // first, second and last tile; every dword of the first, 64th and last row)
   size_t top = 0;
-  for (uint32_t w = 0; w < rows; w++)
-    for (uint32_t k = 0; k < (uint32_t)kSpecTilesMax * 4u; k++) {
+  for (uint32_t w = 0; w < rows; w++) {
+    const uint32_t ks[6] = {0u, 3u, 4u, 7u, kmax - 4u, kmax - 1u};
+    for (uint32_t k : ks) {
       const size_t d = spec_bits_dword(w, k);
       if (d >= words) return false;
+      if (w + 1u < rows && d == spec_bits_dword(w + 1u, k)) return false;
       top = d > top ? d : top;
     }
-  // dense: rows * dwords-per-walker distinct values below `words` with the largest at words - 1 means a bijection
-  // only if the map is injective; both layouts used so far are mixed-radix numberings, checked on the first two waves
-  for (uint32_t w = 0; w < (rows < 128u ? rows : 128u); w++)
-    for (uint32_t k = 0; k < (uint32_t)kSpecTilesMax * 4u; k++)
-      if (w + 1u < rows && spec_bits_dword(w, k) == spec_bits_dword(w + 1u, k)) return false;
-  return top + 1u == (size_t)rows * (size_t)kSpecTilesMax * 4u && top + 1u <= words;
+  }
+  const uint32_t ws[3] = {0u, rows > 64u ? 64u : rows - 1u, rows - 1u};
+  for (uint32_t w : ws)
+    for (uint32_t k = 0; k < kmax; k++) {
+      const size_t d = spec_bits_dword(w, k);
+      if (d >= words || (k + 1u < kmax && d == spec_bits_dword(w, k + 1u))) return false;
+      top = d > top ? d : top;
+    }
+  return top + 1u == (size_t)rows * kmax && top + 1u <= words;  // dense: the last dword of the last row is the buffer's last
 }
 static_assert(spec_bits_layout_ok(1) && spec_bits_layout_ok(63) && spec_bits_layout_ok(64) && spec_bits_layout_ok(65) &&
                   spec_bits_layout_ok(200),

@@ -1,0 +1,131 @@
+"""ctypes view of include/mi_dv.h (libmi_dv.so, the DV25 525/60 decoder).  No CPU path: without the library or a
+gfx950 device construction raises MiDvError with the library's own message."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FRAME_BYTES, PICTURE_BYTES, W, H, CW = 120000, 720 * 480 * 3 // 2, 720, 480, 180
+EXPORTS = ["mi_dv_device_count", "mi_dv_create", "mi_dv_destroy", "mi_dv_last_error", "mi_dv_dev_alloc", "mi_dv_dev_free",
+           "mi_dv_h2d", "mi_dv_d2h", "mi_dv_sync", "mi_dv_decode_batch", "mi_dv_last_kernel_ms", "mi_dv_decode_frame",
+           "mi_dv_copy_tables"]
+_LIB = None
+u8p = C.POINTER(C.c_uint8)
+
+
+class MiDvError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.environ.get("MI_DV_LIB") or os.path.join(HERE, "lib", "libmi_dv.so")
+
+
+def load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    p = lib_path()
+    if not os.path.exists(p):
+        raise MiDvError(f"{p} is missing: run `python gmerlin-avdecoder_amd/build.py` (there is no CPU path)")
+    L = C.CDLL(p)
+    vp = C.c_void_p
+    L.mi_dv_device_count.restype = C.c_int
+    L.mi_dv_create.argtypes = [C.c_int]
+    L.mi_dv_create.restype = vp
+    L.mi_dv_destroy.argtypes = [vp]
+    L.mi_dv_destroy.restype = None
+    L.mi_dv_last_error.argtypes = [vp]
+    L.mi_dv_last_error.restype = C.c_char_p
+    L.mi_dv_dev_alloc.argtypes = [vp, C.c_size_t]
+    L.mi_dv_dev_alloc.restype = vp
+    L.mi_dv_dev_free.argtypes = [vp, vp]
+    L.mi_dv_dev_free.restype = None
+    L.mi_dv_h2d.argtypes = [vp, vp, vp, C.c_size_t]
+    L.mi_dv_d2h.argtypes = [vp, vp, vp, C.c_size_t]
+    L.mi_dv_sync.argtypes = [vp]
+    L.mi_dv_decode_batch.argtypes = [vp, vp, C.c_int, vp]
+    L.mi_dv_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.mi_dv_decode_frame.argtypes = [vp, u8p, C.c_size_t, C.POINTER(u8p), C.POINTER(C.c_int)]
+    L.mi_dv_copy_tables.argtypes = [vp, C.c_size_t]
+    L.mi_dv_copy_tables.restype = C.c_size_t
+    _LIB = L
+    return L
+
+
+def tables():
+    """the decoder's constant tables as the kernels get them (host-side: works without a GPU)"""
+    L = load()
+    n = L.mi_dv_copy_tables(None, 0)
+    a = np.zeros(n // 4, np.uint32)
+    L.mi_dv_copy_tables(a.ctypes.data, n)
+    return {"lut9": a[:512], "lut2": a[512:576], "tab": a[576:704].reshape(2, 64), "shift4": a[704:728]}
+
+
+class MiDv:
+    def __init__(self, device=-1):
+        self.L = load()
+        self.c = self.L.mi_dv_create(device)
+        if not self.c:
+            raise MiDvError(self.L.mi_dv_last_error(None).decode())
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise MiDvError(self.L.mi_dv_last_error(self.c).decode())
+
+    def alloc(self, n):
+        d = self.L.mi_dv_dev_alloc(self.c, n)
+        if not d:
+            raise MiDvError(self.L.mi_dv_last_error(self.c).decode())
+        return d
+
+    def free(self, d):
+        self.L.mi_dv_dev_free(self.c, d)
+
+    def h2d(self, d, a, offset=0):
+        a = np.ascontiguousarray(a)
+        self._chk(self.L.mi_dv_h2d(self.c, d + offset, a.ctypes.data, a.nbytes))
+
+    def d2h(self, d, n, offset=0):
+        a = np.empty(n, np.uint8)
+        self._chk(self.L.mi_dv_d2h(self.c, a.ctypes.data, d + offset, n))
+        return a
+
+    def sync(self):
+        self._chk(self.L.mi_dv_sync(self.c))
+
+    def decode_batch(self, d_frames, n, d_pics):
+        self._chk(self.L.mi_dv_decode_batch(self.c, d_frames, n, d_pics))
+
+    def kernel_ms(self):
+        ms = C.c_float()
+        self._chk(self.L.mi_dv_last_kernel_ms(self.c, C.byref(ms)))
+        return ms.value
+
+    def decode_frames(self, frames):
+        """host frames (n x 120000 uint8) -> host pictures (n x 518400), through the batch path"""
+        frames = np.ascontiguousarray(frames, np.uint8).reshape(-1, FRAME_BYTES)
+        n = frames.shape[0]
+        df, dp = self.alloc(n * FRAME_BYTES), self.alloc(n * PICTURE_BYTES)
+        try:
+            self.h2d(df, frames)
+            self.decode_batch(df, n, dp)
+            self.sync()
+            return self.d2h(dp, n * PICTURE_BYTES).reshape(n, PICTURE_BYTES)
+        finally:
+            self.free(df)
+            self.free(dp)
+
+    def decode_frame(self, frame, strides=(W, CW, CW)):
+        frame = np.ascontiguousarray(frame, np.uint8)
+        planes = [np.zeros(strides[i] * H, np.uint8) for i in range(3)]
+        pp = (u8p * 3)(*[p.ctypes.data_as(u8p) for p in planes])
+        st = (C.c_int * 3)(*strides)
+        self._chk(self.L.mi_dv_decode_frame(self.c, frame.ctypes.data_as(u8p), frame.nbytes, pp, st))
+        return planes
+
+    def close(self):
+        if self.c:
+            self.L.mi_dv_destroy(self.c)
+            self.c = None

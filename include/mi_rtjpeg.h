@@ -130,9 +130,13 @@ mi_rtj_plan *mi_rtj_plan_create(mi_rtj_ctx *ctx, int n, const uint8_t *headers,
                                 const uint64_t *pkt_offset, const uint32_t *pkt_len,
                                 const uint64_t *out_offset);
 void mi_rtj_plan_destroy(mi_rtj_plan *plan);
-/* Queue the whole hot path for the batch on the instance's stream: block-offset index
- * (RTjpeg_s2b's length semantics, lib/RTjpeg.c:157-186) then dequant + IDCT + plane scatter
- * (lib/RTjpeg.c:2209-2332, 2688-2749).  Asynchronous; pair with mi_rtj_sync. */
+/* Queue the whole hot path for the batch: block-offset index (RTjpeg_s2b's length semantics,
+ * lib/RTjpeg.c:157-186) then dequant + IDCT + plane scatter (lib/RTjpeg.c:2209-2332, 2688-2749).
+ * Asynchronous; pair with mi_rtj_sync.  Ordering: the transform always runs on the instance's stream, and
+ * mi_rtj_sync waits for all of a launch.  Plans of some hundred to some thousand pictures build the index of launch
+ * k + 1 on a second stream of their own while launch k is transformed; that stream is ordered behind everything this
+ * library queued on the instance's stream before the call (mi_rtj_dev_memset; mi_rtj_h2d and the encoder entry points
+ * are synchronous).  A caller that writes d_stream with work of its own must finish it before calling. */
 int mi_rtj_plan_decode(mi_rtj_plan *plan, const void *d_stream, void *d_out);
 /* Frames in the plan, total blocks, total algorithmic bytes (packet bytes read + plane bytes written). */
 void mi_rtj_plan_info(const mi_rtj_plan *plan, int *n_frames, uint64_t *n_blocks,

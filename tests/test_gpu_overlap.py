@@ -60,3 +60,27 @@ def test_parity_suite_with_overlapped_plans(dev):
     T.test_skip_blocks_leave_destination_untouched_in_batches(dev)
     T.test_truncated_and_empty_packets(dev)
     T.test_chunk_boundaries_and_long_blocks(dev)
+
+
+def test_a_memset_queued_before_the_launch_is_seen_by_the_index_stream(dev):
+    """mi_rtj_dev_memset is asynchronous on the instance's stream, the index kernels of an overlapped plan
+    run on another one.  The packets' data bytes are overwritten with 0xFF (every block "unchanged") right before the
+    launch, no sync in between: an index that ran ahead of the memset would parse the old packets and pictures
+    would appear; ordered behind it, nothing is decoded and the output keeps its filling."""
+    w, h = 1920, 1088
+    pkts = [R.OracleEncoder(w, h, 255).encode(R.synth_frame(w, h, i, seed=77, amp=8)) for i in range(3)] * 8
+    fsz = T.frame_bytes(w, h)
+    d_stream, po, pl, hdrs = dev.upload_packets(pkts, align=1)
+    d_out = dev.alloc(fsz * len(pkts))
+    plan = dev.plan(hdrs, po, pl, np.arange(len(pkts), dtype=np.uint64) * np.uint64(fsz))
+    dev.memset(d_out, 0x5A, fsz * len(pkts))
+    dev.sync()
+    for i in range(len(pkts)):  # (whole packets but their 12 header bytes, which live on the host side of the plan)
+        dev.memset(d_stream, 0xFF, int(pl[i]) - 12, offset=int(po[i]) + 12)
+    plan.decode(d_stream, d_out)
+    dev.sync()
+    for i in range(len(pkts)):
+        assert (dev.d2h(d_out, fsz, offset=i * fsz) == 0x5A).all(), i
+    plan.close()
+    dev.free(d_stream)
+    dev.free(d_out)

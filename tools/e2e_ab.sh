@@ -25,8 +25,9 @@ run "1080p idx 2, out 2, depth 6" DEPTH=6
 run "1080p idx 4, out 4, depth 8 (two groups in flight)" MI_RTJ_IDX_GROUP=4 MI_RTJ_OUT_GROUP=4 DEPTH=8
 run "1080p idx 2, out 4, depth 12" MI_RTJ_IDX_GROUP=2
 done
-run "1080p no copy out (MI_RTJ_EXP_SKIP=1)" MI_RTJ_EXP_SKIP=1
-run "1080p copy out only (MI_RTJ_EXP_SKIP=6)" MI_RTJ_EXP_SKIP=6
+EXPL=$PWD/gmerlin-avdecoder_amd/lib/libmi_rtjpeg_exp.so  # python gmerlin-avdecoder_amd/build.py --experiments (the switches below only exist in that build; the harness loads libmi_rtjpeg.so by rpath: LD_PRELOAD the other)
+run "1080p no copy out (MI_RTJ_EXP_SKIP=1)" LD_PRELOAD=$EXPL MI_RTJ_EXP_SKIP=1
+run "1080p copy out only (MI_RTJ_EXP_SKIP=6)" LD_PRELOAD=$EXPL MI_RTJ_EXP_SKIP=6
 run "4K default" $K4
 run "4K pairs, depth 6" $K4 DEPTH=6
 run "320x240 default" W=320 H=240 REP=200
