@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — RTjpeg decode throughput on MI355X (BASELINE.json's metric).
 
-    python bench.py --gpus N --steps K --warmup W [--config frames1080|streams4k|mixed]
+    python bench.py --gpus N --steps K --warmup W [--config frames1080|streams4k|mixed|dv]
 
 With --gpus N > 1 and no WORLD_SIZE in the environment this process starts the N ranks itself (one process per
 GPU, `python -m torch.distributed.run`, rendezvous on 127.0.0.1) before anything touches a GPU, passes rank 0's
@@ -19,6 +19,10 @@ Workloads (`config.workload` in the output names the one that ran):
               packets.
   mixed       (configs[4]) 64 intra-only streams of mixed geometry and quality, frames dealt cyclically to the
               ranks, one plan per rank, every frame of every rank compared with the CPU oracle.
+
+  dv          (configs[2]) `--frames` (1024) DV25 525/60 DIF frames of 120,000 bytes resident in HBM -> 720x480 4:1:1
+              pictures, one kernel (libmi_dv.so); "parity": "unpinned" — the reference holds no DV pixel decoder, the
+              checker is this repository's own statement of the format (bench_dv.py).
 
 One process per GPU.  No data-path collective: RCCL carries the barrier and the final (frames, pixels,
 mismatches, max elapsed) reduction only.
@@ -65,7 +69,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", choices=["frames1080", "streams4k", "mixed"], default="frames1080")
+    ap.add_argument("--config", choices=["frames1080", "streams4k", "mixed", "dv"], default="frames1080")
     ap.add_argument("--frames", type=int, default=None, help="frames resident per GPU (frames1080: 16384) / per stream")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1088)
@@ -311,6 +315,9 @@ def main():
     # MI_RTJ_DIST_BACKEND=gloo + MI_RTJ_SHARE_DEVICE=1 rehearse the multi-rank flow on a one-GPU box
     # (all ranks on device 0, reduction over gloo); the real run is one rank per GPU over RCCL.
     gpu = 0 if os.environ.get("MI_RTJ_SHARE_DEVICE") else local
+    # a rank runs next to its GPU: the cores (and, by first touch, the pinned memory) of the GPU's NUMA node — before
+    # the first GPU call (matters for the host-to-host workloads on a two-socket node)
+    numa = shard.bind_rank_to_gpu_node(gpu) if world > 1 or os.environ.get("MI_RTJ_BIND_NUMA") else {"bound": False, "reason": "one rank"}
     force_dist = bool(os.environ.get("MI_RTJ_FORCE_DIST"))  # the process-group path even with one rank
     if world > 1 or force_dist:
         import torch.distributed as dist
@@ -319,6 +326,19 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", gpu))  # nccl == RCCL on ROCm
         else:
             dist.init_process_group(backend)
+    if a.config == "dv":
+        def barrier_dv():
+            if dist is not None:
+                dist.barrier()
+        red = f"cuda:{gpu}" if dist is not None and backend == "nccl" else None
+        out, mism = importlib.import_module("bench_dv").run(a, rank, world, gpu, dist, red, shard, barrier_dv, force_dist)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        if mism:
+            raise SystemExit(3)
+        return
     P = importlib.import_module("gmerlin-avdecoder_amd")
     dev = P.MiRtj(gpu)  # raises if the HIP library or the device is missing: no CPU fallback
 
@@ -420,6 +440,7 @@ def main():
                                       chunks_repaired=getattr(plan, "repaired", 0),
                                       walker_lead_bytes=plan.spec_lead()[0]),  # what the policy chose for the next launch
             "path_gbs": round(alg_bytes * a.steps / dt / 1e9, 2),
+            "host_binding": numa,  # rank 0's: cores of its GPU's NUMA node (gmerlin-avdecoder_amd/shard.py)
         }
         # the vector-issue roof of k_decode: instructions per launch from the PMC profile of these sources
         vi = prof.get("valu_instructions", {}).get("k_decode") if prof and prof["_current"] else None

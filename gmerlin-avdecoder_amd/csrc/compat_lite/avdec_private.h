@@ -19,6 +19,7 @@ typedef enum { GAVL_SOURCE_EOF = 0, GAVL_SOURCE_OK = 1, GAVL_SOURCE_AGAIN = 2 } 
 
 #define GAVL_MAX_PLANES 4
 #define GAVL_YUV_420_P 0x0501 /* opaque tag here */
+#define GAVL_YUV_411_P 0x0505 /* opaque tag here */
 #define GAVL_META_FORMAT "Format"
 #define GAVL_LOG_ERROR 1
 #define GAVL_LOG_INFO 4
@@ -57,6 +58,7 @@ typedef struct gavl_dictionary_s {
   char format[64];
   int n_ints;
   struct { char key[32]; int val; } ints[MI_COMPAT_DICT_INTS];
+  const gavl_video_format_t *vfmt; /* a stream dictionary's video format (gavl_stream_get_video_format) */
 } gavl_dictionary_t;
 typedef gavl_dictionary_t bgav_options_t; /* "Options are now passed as dictionary", include/avdec.h:252-254 */
 
@@ -111,5 +113,6 @@ gavl_video_frame_t *gavl_video_frame_create(const gavl_video_format_t *format); 
 void gavl_video_frame_null(gavl_video_frame_t *f);
 void gavl_video_frame_destroy(gavl_video_frame_t *f);
 void gavl_log(int level, const char *domain, const char *fmt, ...);
+const gavl_video_format_t *gavl_stream_get_video_format(const gavl_dictionary_t *stream); /* gavl/metatags.h */
 
 #endif

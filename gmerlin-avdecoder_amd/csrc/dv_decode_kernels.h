@@ -49,7 +49,11 @@ __device__ __forceinline__ void dv_or_bits(uint32_t* buf, uint32_t bp, uint32_t 
 }
 
 __global__ __launch_bounds__(64) void k_dv_decode(const uint8_t* __restrict__ frames, uint8_t* __restrict__ pics,
-                                                   const Tables* __restrict__ T) {
+                                                   const Tables* __restrict__ T
+#ifdef MIDV_DEBUG
+                                                   , int16_t* __restrict__ dbg  // [frame][workgroup][lane][64 coefficients + 8 state words]
+#endif
+) {
   __shared__ __attribute__((aligned(16))) uint8_t s_coef[64 * kLaneStride];
   __shared__ uint32_t s_lut9[512], s_lut2[64], s_tab[128], s_sh[24];
   __shared__ uint32_t s_mbuf[10][kMbufWords], s_vbuf[2][kVbufWords];
@@ -130,8 +134,10 @@ __global__ __launch_bounds__(64) void k_dv_decode(const uint8_t* __restrict__ fr
   };
 
   // ---- pass 1: every block from its own area ----
+  // (every loop of this kernel carries a bound no stream can reach — a code word is at least three bits long — so that a
+  // wave always comes to its end whatever the tables or the bytes hold)
   bool act = live;
-  while (__any(act)) {
+  for (int guard = 0; guard < 48 && __any(act); guard++) {
     if (act) {
       const uint32_t e = lookup(W0), len = e & 31u;
       if (p + len > A) {
@@ -184,15 +190,15 @@ __global__ __launch_bounds__(64) void k_dv_decode(const uint8_t* __restrict__ fr
   __syncthreads();
   // lanes that want bits take turns, lowest lane of a group first, reading from the group's buffer until their block
   // is finished or the buffer is used up
-  auto drain = [&](uint32_t gmask, const uint32_t* buf, uint32_t* gpos, const uint32_t glen) {
-    for (;;) {
+  auto drain = [&](const unsigned long long gmask, const uint32_t* buf, uint32_t* gpos, const uint32_t glen) {
+    for (int turn = 0; turn < 64; turn++) {
       const bool want = live && !fin && *gpos < glen;
       const unsigned long long m = __ballot(want);
       if (m == 0ull) break;
       const unsigned long long mine = m & gmask;
       if (want && (uint32_t)lane == (uint32_t)__builtin_ctzll(mine)) {
         uint32_t bp = *gpos;
-        for (;;) {
+        for (int guard = 0; guard < 1024; guard++) {
           const uint32_t avail = glen - bp;
           uint32_t w = dv_peek(buf, bp);
           if (npart) w = part | (w >> npart);
@@ -250,6 +256,15 @@ __global__ __launch_bounds__(64) void k_dv_decode(const uint8_t* __restrict__ fr
   drain(seg ? 0x3FFFFFFFull << 30 : 0x3FFFFFFFull, s_vbuf[seg < 2u ? seg : 1u], &s_vpos[seg < 2u ? seg : 1u],
         live ? s_vlen[seg] : 0u);
 
+#ifdef MIDV_DEBUG
+  if (dbg) {
+    __syncthreads();
+    int16_t* o = dbg + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 + lane) * 72;
+    for (int i = 0; i < 64; i++) o[i] = ((const int16_t*)my)[i];
+    o[64] = (int16_t)pos; o[65] = (int16_t)p; o[66] = (int16_t)fin; o[67] = (int16_t)npart; o[68] = (int16_t)mode; o[69] = (int16_t)cls;
+    o[70] = (int16_t)qno; o[71] = (int16_t)(live ? (mb10 < 10u ? s_mlen[mb10] : 0) : 0);
+  }
+#endif
   // ---- inverse transform and placement ----
   if (!live) return;
   int c[64];
@@ -322,6 +337,9 @@ __global__ __launch_bounds__(64) void k_dv_decode(const uint8_t* __restrict__ fr
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       int s = (int)((uint32_t)y[k] << 13) >> 16;  // (int16)(v >> 3): DESCALE with int16 narrowing (the + 4 came in with DC)
+      // (the empty asm keeps hipcc (ROCm 7.2) from fusing "shift, clamp, pack" into gfx950's v_ashr_pk_u8_i32, which came
+      // out wrong on the MI355X here as it did in the colour stage, rtj_color_kernels.h: third byte of every dword)
+      asm volatile("" : "+v"(s));
       s = s < 0 ? 0 : s > 255 ? 255 : s;
       px[k] = (uint32_t)s;
     }

@@ -7,6 +7,8 @@
 
 #include <mutex>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "../../include/mi_dv.h"
 #include "dv_common.h"
@@ -25,8 +27,8 @@ struct mi_dv_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   Tables* d_tab = nullptr;
-  hipEvent_t ev_a = nullptr, ev_b = nullptr;
-  bool timed = false;
+  // one pair of events around every launch since the last mi_dv_kernel_times (recycled there)
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_used, ev_free;
   // the one-frame path's buffers
   uint8_t* d_frame = nullptr;
   uint8_t* d_pic = nullptr;
@@ -97,8 +99,7 @@ mi_dv_ctx* mi_dv_create(int device) {
   c->device = device;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipMalloc((void**)&c->d_tab, sizeof(Tables)) != hipSuccess ||
-      hipMemcpy(c->d_tab, &t, sizeof t, hipMemcpyHostToDevice) != hipSuccess ||
-      hipEventCreate(&c->ev_a) != hipSuccess || hipEventCreate(&c->ev_b) != hipSuccess) {
+      hipMemcpy(c->d_tab, &t, sizeof t, hipMemcpyHostToDevice) != hipSuccess) {
     fail(nullptr, MI_DV_ERR_HIP, "cannot set up device %d: %s", device, hipGetErrorString(hipGetLastError()));
     mi_dv_destroy(c);
     return nullptr;
@@ -114,8 +115,11 @@ void mi_dv_destroy(mi_dv_ctx* c) {
   if (c->d_frame) (void)hipFree(c->d_frame);
   if (c->d_pic) (void)hipFree(c->d_pic);
   if (c->h_pic) (void)hipHostFree(c->h_pic);
-  if (c->ev_a) (void)hipEventDestroy(c->ev_a);
-  if (c->ev_b) (void)hipEventDestroy(c->ev_b);
+  for (auto* v : {&c->ev_used, &c->ev_free})
+    for (auto& e : *v) {
+      (void)hipEventDestroy(e.first);
+      (void)hipEventDestroy(e.second);
+    }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -156,27 +160,55 @@ int mi_dv_sync(mi_dv_ctx* c) {
   return MI_DV_OK;
 }
 
+#ifdef MIDV_DEBUG
+static void* g_dbg = nullptr;
+extern "C" void mi_dv_debug_buffer(void* d) { g_dbg = d; }
+#endif
 int mi_dv_decode_batch(mi_dv_ctx* c, const void* d_frames, int n, void* d_pics) {
   if (!c || !d_frames || !d_pics || n <= 0) return fail(c, MI_DV_ERR_ARG, "mi_dv_decode_batch: bad argument");
   if (n > 65535) return fail(c, MI_DV_ERR_ARG, "mi_dv_decode_batch: %d frames; at most 65535 per call (split the batch)", n);
   if (((uintptr_t)d_frames & 3u) || ((uintptr_t)d_pics & 7u))
     return fail(c, MI_DV_ERR_ARG, "mi_dv_decode_batch: d_frames must be 4-byte and d_pics 8-byte aligned");
   DVCHK(c, hipSetDevice(c->device));
-  DVCHK(c, hipEventRecord(c->ev_a, c->stream));
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  if (!c->ev_free.empty()) {
+    ev = c->ev_free.back();
+    c->ev_free.pop_back();
+  } else {
+    DVCHK(c, hipEventCreate(&ev.first));
+    DVCHK(c, hipEventCreate(&ev.second));
+  }
+  c->ev_used.push_back(ev);
+  if (c->ev_used.size() > 4096) {  // nobody asks for times: keep the newest
+    c->ev_free.push_back(c->ev_used.front());
+    c->ev_used.erase(c->ev_used.begin());
+  }
+  DVCHK(c, hipEventRecord(ev.first, c->stream));
   hipLaunchKernelGGL(k_dv_decode, dim3(kSegments / 2, (unsigned)n), dim3(64), 0, c->stream, (const uint8_t*)d_frames,
-                     (uint8_t*)d_pics, c->d_tab);
+                     (uint8_t*)d_pics, c->d_tab
+#ifdef MIDV_DEBUG
+                     , (int16_t*)g_dbg
+#endif
+  );
   DVCHK(c, hipGetLastError());
-  DVCHK(c, hipEventRecord(c->ev_b, c->stream));
-  c->timed = true;
+  DVCHK(c, hipEventRecord(ev.second, c->stream));
   return MI_DV_OK;
 }
 
-int mi_dv_last_kernel_ms(mi_dv_ctx* c, float* ms) {
-  if (!c || !ms) return MI_DV_ERR_ARG;
-  if (!c->timed) return fail(c, MI_DV_ERR_ARG, "mi_dv_last_kernel_ms: nothing was decoded yet");
+int mi_dv_kernel_times(mi_dv_ctx* c, float* total_ms, int* launches) {
+  if (!c || !total_ms || !launches) return MI_DV_ERR_ARG;
   DVCHK(c, hipSetDevice(c->device));
-  DVCHK(c, hipEventSynchronize(c->ev_b));
-  DVCHK(c, hipEventElapsedTime(ms, c->ev_a, c->ev_b));
+  DVCHK(c, hipStreamSynchronize(c->stream));
+  float sum = 0.f;
+  for (auto& e : c->ev_used) {
+    float ms = 0.f;
+    DVCHK(c, hipEventElapsedTime(&ms, e.first, e.second));
+    sum += ms;
+  }
+  *total_ms = sum;
+  *launches = (int)c->ev_used.size();
+  for (auto& e : c->ev_used) c->ev_free.push_back(e);
+  c->ev_used.clear();
   return MI_DV_OK;
 }
 

@@ -100,7 +100,8 @@ struct mi_rtj_plan {
   uint8_t* d_spec_flag = nullptr;          // [walkers + 64]: 1 = on that list in this launch
   uint32_t* d_spec_nfix = nullptr;
   uint32_t* d_spec_ok = nullptr;           // [n]: 1 = the packet's index is proven
-  uint32_t* d_spec_todo = nullptr;         // [n + 1]: count, then the packets left to the exact kernels
+  uint32_t* d_spec_todo = nullptr;         // [n + 2]: count, then the packets left to the exact kernels; [n + 1]: how many
+                                           // of them the serial walker takes instead (k_spec_policy)
   int cap_spec_frames = 0;
   uint32_t* d_spec_state = nullptr;        // [2]: launches in a row that refused every packet, launches left paused
   // batches: what k_decode_split leaves to k_decode_list (rtj_decode_kernels.h, DecList): every part of every group of a
@@ -109,7 +110,10 @@ struct mi_rtj_plan {
   uint32_t* d_declist_cnt = nullptr;
   uint64_t declist_cap = 0;
   int declist_flip = 0;
-  int split = -1;                          // MI_RTJ_SPLIT (A/B): 0 = batches run k_decode<true, false> as in round 3
+  bool batch_seen = false;                 // a batch launch (a wave takes several parts of its groups, no previous picture) was queued
+  uint32_t serial_min = 4096;              // MI_RTJ_SERIAL_MIN: to-do lists from this many packets on go to the serial walker (0: never)
+  int split = -1;                          // MI_RTJ_SPLIT (A/B): 0 = batches always run k_decode<true, false> (round 3's form),
+                                           // 1 = always k_decode_split; otherwise the plan's policy decides on the device
   int rotate = -1;                         // MI_RTJ_ROTATE: 1 / 0 = a k_decode wave takes all three parts of its groups / one part; -1 = by batch size
   const uint8_t* prev_pic = nullptr;       // sessions: where unchanged blocks of this launch are copied from
   hipStream_t idx_stream = nullptr;        // the stream of the index kernels (sessions: theirs, not owned; batches: own_idx); null = the instance's
@@ -398,7 +402,8 @@ int plan_alloc_chunks(mi_rtj_plan* p) {
       HIPCHK(c, hipMalloc((void**)&p->d_spec_base, sizeof(uint32_t) * (p->h_frames.size() + 1)));
       HIPCHK(c, hipMalloc((void**)&p->d_spec_ok, sizeof(uint32_t) * p->h_frames.size()));
       HIPCHK(c, hipMemsetAsync(p->d_spec_ok, 0, sizeof(uint32_t) * p->h_frames.size(), c->stream));  // "nothing proven yet" for mi_rtj_plan_spec_stats
-      HIPCHK(c, hipMalloc((void**)&p->d_spec_todo, sizeof(uint32_t) * (p->h_frames.size() + 1)));
+      HIPCHK(c, hipMalloc((void**)&p->d_spec_todo, sizeof(uint32_t) * (p->h_frames.size() + 2)));
+      HIPCHK(c, hipMemsetAsync(p->d_spec_todo + p->h_frames.size() + 1, 0, sizeof(uint32_t), c->stream));
       if (!p->d_spec_state) {
         HIPCHK(c, hipMalloc((void**)&p->d_spec_state, sizeof(uint32_t) * kSpecStWords));
         HIPCHK(c, hipMemsetAsync(p->d_spec_state, 0, sizeof(uint32_t) * kSpecStWords, c->stream));
@@ -522,9 +527,17 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out, int what = kL
                            p->d_spec_rec, p->d_spec_nrec, blk, p->d_spec_ok, p->d_spec_todo + 1, p->d_spec_todo, state,
                            p->d_spec_wstart, p->d_spec_hand, p->d_spec_fix, p->d_spec_nfix, p->d_spec_flag, 2);
         if ((rc = end(MI_RTJ_K_SPEC_VERIFY)) != MI_RTJ_OK) return rc;
-        if (state) hipLaunchKernelGGL(k_spec_policy, dim3(1), dim3(256), 0, is, (uint32_t)p->n, (uint32_t)p->n_spec, p->d_spec_todo, p->d_spec_nfix, state);
+        if (state) hipLaunchKernelGGL(k_spec_policy, dim3(1), dim3(256), 0, is, (uint32_t)p->n, (uint32_t)p->n_spec, p->d_spec_todo, p->d_spec_nfix, state,
+                                      p->serial_min);
       }
       if ((rc = begin(MI_RTJ_K_SUMMARIZE)) != MI_RTJ_OK) return rc;
+      // A long to-do list (the speculation paused on noisy content, a big launch) goes to the serial walker, one wave
+      // per packet: with thousands of packets in flight it indexes faster than the chunk-parallel kernels, whose work
+      // grows with the stream's bytes (profiles/r04/noisy_serial_ab.txt: +15 % at 4096 packets of +-64 noise, +28 % at
+      // 16384).  k_spec_policy moved the count to the walker's word; the exact kernels then see an empty list.
+      if (todo && state)
+        hipLaunchKernelGGL(k_index_walk_todo, dim3(std::min<unsigned>((unsigned)p->n, 16384u)), dim3(64), 0, is, p->d_frames,
+                           st, c->d_lut, blk, todo, p->d_spec_todo + 1 + p->n);
       if (todo) {
         if (p->one_block_type)
           hipLaunchKernelGGL(k_index_summarize_todo<1>, dim3(p->max_chunks, rows), dim3(kSumThreads), 0, is,
@@ -582,6 +595,7 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out, int what = kL
     uint8_t* const out8 = (uint8_t*)d_out;
     // four instantiations: (a wave takes all three parts of its groups | one part) x (unchanged blocks stay | are
     // fetched from the previous packet's picture); a launch runs the one that carries nothing else
+    if (span == 3u && !p->prev_pic) p->batch_seen = true;
     if (span == 3u && !p->prev_pic && p->split != 0) {
       // batches: luma waves (two parts of their groups in turn) and chroma waves that pool three groups' busy blocks
       // into one transform round; what neither covers goes to the list and k_decode_list (rtj_decode_chroma.h)
@@ -595,38 +609,45 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out, int what = kL
         HIPCHK(c, hipMalloc((void**)&p->d_declist, sizeof(uint2) * need));
         p->declist_cap = need;
       }
-      if (!p->d_declist_cnt) {
-        HIPCHK(c, hipMalloc((void**)&p->d_declist_cnt, 2 * sizeof(uint32_t)));
-        HIPCHK(c, hipMemsetAsync(p->d_declist_cnt, 0, 2 * sizeof(uint32_t), ds));
+      if (!p->d_declist_cnt) {  // two list counters, then the policy's two words (mode, launches left in it)
+        HIPCHK(c, hipMalloc((void**)&p->d_declist_cnt, 4 * sizeof(uint32_t)));
+        HIPCHK(c, hipMemsetAsync(p->d_declist_cnt, 0, 4 * sizeof(uint32_t), ds));
       }
+      uint32_t* const policy = p->split < 0 ? p->d_declist_cnt + 2 : nullptr;  // (forced split: no policy)
       const DecList list{p->d_declist_cnt + p->declist_flip, p->d_declist, (uint32_t)p->declist_cap};
       const uint32_t slots_c = chroma_pool_slots(p->max_groups);
       // (timing builds only, wrong pictures: MI_RTJ_SPLIT_ONLY = 1 the luma waves alone, 2 the chroma waves alone)
       if (const char* only = exp_env("MI_RTJ_SPLIT_ONLY")) {
         if (atoi(only) == 1)
-          hipLaunchKernelGGL(k_decode_split, dim3(dslots, drows), block, 0, ds, dfr, st, c->d_lut, blk, out8, dslots, list);
+          hipLaunchKernelGGL(k_decode_split, dim3(dslots, drows), block, 0, ds, dfr, st, c->d_lut, blk, out8, dslots, list,
+                             (const uint32_t*)nullptr);
         else
-          hipLaunchKernelGGL(k_decode_split, dim3(slots_c, drows), block, 0, ds, dfr, st, c->d_lut, blk, out8, 0u, list);
+          hipLaunchKernelGGL(k_decode_split, dim3(slots_c, drows), block, 0, ds, dfr, st, c->d_lut, blk, out8, 0u, list,
+                             (const uint32_t*)nullptr);
       } else
       hipLaunchKernelGGL(k_decode_split, dim3(dslots + slots_c, drows), block, 0, ds, dfr, st, c->d_lut, blk, out8,
-                         dslots, list);
+                         dslots, list, (const uint32_t*)policy);
+      // the classic form: runs while the policy says so (returns at once otherwise: ~30 us of empty workgroups)
+      if (policy)
+        hipLaunchKernelGGL((k_decode<true, false>), grid, block, 0, ds, dfr, st, c->d_lut, blk, out8,
+                           (const uint8_t*)nullptr, (const uint32_t*)policy);
       hipLaunchKernelGGL(k_decode_list, dim3(kDecListGrid), block, 0, ds, dfr, st, c->d_lut, blk, out8, list,
-                         p->d_declist_cnt + (p->declist_flip ^ 1));
+                         p->d_declist_cnt + (p->declist_flip ^ 1), policy, (uint32_t)need);
       p->declist_flip ^= 1;
     } else if (span == 3u) {
       if (p->prev_pic)
         hipLaunchKernelGGL((k_decode<true, true>), grid, block, 0, ds, dfr, st, c->d_lut, blk, out8,
-                           p->prev_pic);
+                           p->prev_pic, (const uint32_t*)nullptr);
       else
         hipLaunchKernelGGL((k_decode<true, false>), grid, block, 0, ds, dfr, st, c->d_lut, blk, out8,
-                           (const uint8_t*)nullptr);
+                           (const uint8_t*)nullptr, (const uint32_t*)nullptr);
     } else {
       if (p->prev_pic)
         hipLaunchKernelGGL((k_decode<false, true>), grid, block, 0, ds, dfr, st, c->d_lut, blk, out8,
-                           p->prev_pic);
+                           p->prev_pic, (const uint32_t*)nullptr);
       else
         hipLaunchKernelGGL((k_decode<false, false>), grid, block, 0, ds, dfr, st, c->d_lut, blk,
-                           out8, (const uint8_t*)nullptr);
+                           out8, (const uint8_t*)nullptr, (const uint32_t*)nullptr);
     }
   }
   if ((rc = end(MI_RTJ_K_DECODE)) != MI_RTJ_OK) return rc;
@@ -835,6 +856,8 @@ mi_rtj_plan* mi_rtj_plan_create(mi_rtj_ctx* c, int n, const uint8_t* headers, co
     p->dec_slots = ds ? (uint32_t)atoi(ds) : 0u;
     const char* ro = getenv("MI_RTJ_ROTATE");
     p->rotate = ro ? (atoi(ro) != 0) : -1;
+    const char* sm = getenv("MI_RTJ_SERIAL_MIN");
+    if (sm) p->serial_min = (uint32_t)atoi(sm);
     const char* spl = getenv("MI_RTJ_SPLIT");
     p->split = spl ? (atoi(spl) != 0) : -1;
   }
@@ -986,6 +1009,27 @@ int mi_rtj_plan_spec_lead(mi_rtj_plan* p, int* lead_bytes, int* paused_launches)
   return MI_RTJ_OK;
 }
 
+int mi_rtj_plan_decode_form(mi_rtj_plan* p, int* form, int* classic_launches_left, long long* parts_listed) {
+  if (!p || !form || !classic_launches_left || !parts_listed) return MI_RTJ_ERR_ARG;
+  mi_rtj_ctx* c = p->ctx;
+  *form = -1;  // no batch launch yet, or a plan whose launches are not batches: k_decode's other forms
+  *classic_launches_left = 0;
+  *parts_listed = 0;
+  if (!p->batch_seen) return MI_RTJ_OK;
+  if (p->split == 0 || !p->d_declist_cnt) {  // forced: always the classic form
+    *form = 1;
+    return MI_RTJ_OK;
+  }
+  uint32_t w[4];
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(w, p->d_declist_cnt, sizeof(w), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *form = p->split == 1 ? 0 : p->split == 0 ? 1 : (int)w[2];
+  *classic_launches_left = p->split < 0 ? (int)w[3] : 0;
+  *parts_listed = (long long)w[p->declist_flip ^ 1];  // the counter of the launch queued last (the next launch's is zero)
+  return MI_RTJ_OK;
+}
+
 int mi_rtj_plan_spec_stats(mi_rtj_plan* p, int* proven, long long* walkers, long long* repaired) {
   if (!p || !proven || !walkers || !repaired) return MI_RTJ_ERR_ARG;
   mi_rtj_ctx* c = p->ctx;
@@ -1006,6 +1050,17 @@ int mi_rtj_plan_spec_stats(mi_rtj_plan* p, int* proven, long long* walkers, long
   for (uint32_t v : ok) *proven += v == 1u ? 1 : 0;
   return MI_RTJ_OK;
 }
+
+#ifdef MIRTJ_EXPERIMENTS
+// timing builds only (not declared in include/mi_rtjpeg.h): ticks per section of the pooling chroma waves since the last call
+extern "C" int mi_rtj_debug_pool_stamps(unsigned long long out[16]) {
+  if (hipDeviceSynchronize() != hipSuccess) return MI_RTJ_ERR_HIP;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pool_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return MI_RTJ_ERR_HIP;
+  unsigned long long zero[16] = {};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_pool_stamps), zero, sizeof zero) != hipSuccess) return MI_RTJ_ERR_HIP;
+  return MI_RTJ_OK;
+}
+#endif
 
 int mi_rtj_plan_read_index(mi_rtj_plan* p, uint32_t* dst, size_t max_entries) {
   if (!p || !dst) return MI_RTJ_ERR_ARG;

@@ -38,6 +38,20 @@ __host__ __device__ constexpr uint32_t chroma_pool_slots(uint32_t groups) {
   return ((sg + (uint32_t)kPoolItersMax - 1u) / (uint32_t)kPoolItersMax) | 1u;
 }
 
+#ifdef MIRTJ_EXPERIMENTS  // timing builds: shader-clock ticks per section of a pooling wave, summed over all waves
+__device__ unsigned long long g_pool_stamps[16];
+#define MIRTJ_PSTAMP(i)                                         \
+  do {                                                          \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    pst[i] += t_ - pst_last;                                    \
+    pst_last = t_;                                              \
+  } while (0)
+#else
+#define MIRTJ_PSTAMP(i) \
+  do {                  \
+  } while (0)
+#endif
+
 typedef uint32_t mirtj_u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t mirtj_u32x3 __attribute__((ext_vector_type(3)));
 
@@ -115,6 +129,9 @@ __device__ __forceinline__ void chroma_pool_wave(uint32_t* __restrict__ s_lds, c
     }
   };
 
+#ifdef MIRTJ_EXPERIMENTS
+  unsigned long long pst[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pst_last = __builtin_amdgcn_s_memtime();
+#endif
   mirtj_u32x3 B[kPoolGroups];  // stream bytes of the round in hand: 12 bytes from the dword that holds the block's first
   mirtj_u32x2 O[kPoolGroups];  // (block start, next block's start) of the round after it
   Meta cur_m;
@@ -143,6 +160,7 @@ __device__ __forceinline__ void chroma_pool_wave(uint32_t* __restrict__ s_lds, c
     asm volatile("" ::"v"(B[0]), "v"(B[1]), "v"(B[2]), "v"(O[0]), "v"(O[1]), "v"(O[2]));
   }
 
+  MIRTJ_PSTAMP(0);  // prologue
   uint32_t exit_sg = 0u, exit_bailed = 0u;
   uint32_t nstores = 0u;  // row-store instructions of the round before (wave-uniform): what the counted wait leaves in flight
   for (uint32_t sg = slot;; sg += slots) {
@@ -190,6 +208,7 @@ __device__ __forceinline__ void chroma_pool_wave(uint32_t* __restrict__ s_lds, c
           : "memory");
     }
 
+    MIRTJ_PSTAMP(1);  // bytes of the round, next round's addresses, loads issued
     // ---- classify: 0 nothing to store (no block, unchanged block, group left to the list), 1 DC only, 2 busy ----
     uint32_t info[kPoolGroups];  // pixel | class << 8 | rank among the round's busy blocks << 10
     uint32_t cnt[kPoolGroups];   // busy blocks of the group (wave-uniform)
@@ -206,6 +225,7 @@ __device__ __forceinline__ void chroma_pool_wave(uint32_t* __restrict__ s_lds, c
       info[q] = px(dc + 4) | (cls << 8) | (rank << 10);
       gstore |= __ballot(cls != 0u) != 0ull ? 1u << q : 0u;
     }
+    MIRTJ_PSTAMP(2);  // classification
     // ---- rounds of pooled groups: as many consecutive groups as have 64 busy blocks or fewer between them ----
     uint32_t stored = 0u, bailed = 0u;  // groups whose rows were stored / that turned out to need the general path (bit q)
     for (uint32_t qa = 0u; qa < (uint32_t)kPoolGroups;) {
@@ -282,6 +302,7 @@ __device__ __forceinline__ void chroma_pool_wave(uint32_t* __restrict__ s_lds, c
           bad = bad || hi != 0u;
         }
         bail = __any(bad);  // wave-uniform
+        MIRTJ_PSTAMP(3);  // hand-over through LDS, parse
         if (bail) {
           bailed |= mask;  // (appended behind the counted wait)
         } else if (vlive) {
@@ -296,6 +317,7 @@ __device__ __forceinline__ void chroma_pool_wave(uint32_t* __restrict__ s_lds, c
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       }
+      MIRTJ_PSTAMP(4);  // transform, rows into LDS
       if (bail) continue;
       // ---- the rows of the pooled groups leave: whole row segments, as from a plain round ----
 #pragma unroll
@@ -340,6 +362,7 @@ __device__ __forceinline__ void chroma_pool_wave(uint32_t* __restrict__ s_lds, c
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the scratch is written again by the next round's parse
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      MIRTJ_PSTAMP(5);  // row stores
     }
     auto push_bailed = [&](uint32_t sgx, uint32_t bits) {
 #pragma unroll
@@ -386,9 +409,16 @@ __device__ __forceinline__ void chroma_pool_wave(uint32_t* __restrict__ s_lds, c
       MIRTJ_COPY(O[q].y, nO[q].y);
     }
 #undef MIRTJ_COPY
+    MIRTJ_PSTAMP(6);  // the counted wait
     if (bailed) push_bailed(sg, bailed);
     cur_m = nxt_m;
   }
+#ifdef MIRTJ_EXPERIMENTS
+  if (lane == 0) {
+    for (int i = 0; i < 7; i++) atomicAdd(&g_pool_stamps[i], pst[i]);
+    atomicAdd(&g_pool_stamps[7], 1ull);
+  }
+#endif
   if (exit_bailed)  // the last round's, behind the loop
     for (int q = 0; q < kPoolGroups; q++)
       if (exit_bailed >> q & 1u) declist_push(list, fidx, exit_sg * (uint32_t)kPoolGroups + (uint32_t)q, 2u);
@@ -405,7 +435,9 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode_split(c
                                                                const QTab* __restrict__ lut,
                                                                const uint32_t* __restrict__ blkoff,
                                                                uint8_t* __restrict__ outbuf, const uint32_t slots_y,
-                                                               const DecList list) {
+                                                               const DecList list,
+                                                               const uint32_t* __restrict__ only_in_mode) {
+  if (only_in_mode && *only_in_mode != kDecModeSplit) return;  // the plan's policy has the classic form run (DecPolicy)
   __shared__ __attribute__((aligned(16))) uint32_t s_lds[kDecLdsWords];
   if (blockIdx.x < slots_y)
     decode_wave<true, false, 2, true>(s_lds, frames, blockIdx.y, blockIdx.x, slots_y, 0u, stream, lut, blkoff, outbuf,
@@ -423,11 +455,24 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode_list(co
                                                               const QTab* __restrict__ lut,
                                                               const uint32_t* __restrict__ blkoff,
                                                               uint8_t* __restrict__ outbuf, const DecList list,
-                                                              uint32_t* __restrict__ next_count) {
+                                                              uint32_t* __restrict__ next_count,
+                                                              uint32_t* __restrict__ policy, const uint32_t parts_total) {
   __shared__ __attribute__((aligned(16))) uint32_t s_lds[kDecLdsWords];
-  // (the next launch's counter: nobody reads it during this launch, and the next launch's kernels run behind this one)
-  if (blockIdx.x == 0 && threadIdx.x == 0) *next_count = 0u;
   uint32_t n = *list.count;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // (the next launch's counter: nobody reads it during this launch, and the next launch's kernels run behind this one)
+    *next_count = 0u;
+    if (policy) {  // the books of the plan's decode policy (rtj_decode_kernels.h): nobody else reads them in this kernel
+      if (policy[0] == kDecModeSplit) {
+        if (n > parts_total / kDecListShare) {
+          policy[0] = kDecModeClassic;
+          policy[1] = kDecClassicLaunches;
+        }
+      } else if (--policy[1] == 0u) {
+        policy[0] = kDecModeSplit;
+      }
+    }
+  }
   n = n < list.cap ? n : list.cap;
   for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
     const uint2 it = list.items[e];

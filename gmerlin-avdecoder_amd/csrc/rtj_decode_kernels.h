@@ -208,6 +208,19 @@ __global__ __launch_bounds__(64) void k_index_walk(const FrameDev* __restrict__ 
   walk_blocks(f, stream, lut, 0u, 0u, f.nmb * 6u, true, blkoff + f.blk_base);
 }
 
+// The packets of a to-do list, a wave each (grid-stride): what k_spec_policy hands the serial walker when the list is long.
+__global__ __launch_bounds__(64) void k_index_walk_todo(const FrameDev* __restrict__ frames,
+                                                         const uint8_t* __restrict__ stream,
+                                                         const QTab* __restrict__ lut, uint32_t* __restrict__ blkoff,
+                                                         const uint32_t* __restrict__ todo,
+                                                         const uint32_t* __restrict__ ntodo) {
+  const uint32_t n = *ntodo;
+  for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const FrameDev f = frames[todo[i]];
+    walk_blocks(f, stream, lut, 0u, 0u, f.nmb * 6u, true, blkoff + f.blk_base);
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // 8-point inverse AAN butterfly (lib/RTjpeg.c:2240-2283 for columns, :2290-2327 for rows;
 // constants :1196-1199, MULTIPLY :1206).  Every multiplicand stays below 2^23 in magnitude
@@ -473,6 +486,13 @@ struct DecList {
   uint2* items;
   uint32_t cap;
 };
+// The plan's decode policy, on the device (two words: mode, launches left in it): batches start with k_decode_split; a
+// launch that leaves more than 1 / kDecListShare of its group parts to the list — content whose chroma the pooling waves
+// do not cover: noisy pictures — makes the next kDecClassicLaunches launches run k_decode<true, false> instead, then the
+// split form is tried again.  k_decode_list, the last kernel of a launch, keeps the books.
+enum : uint32_t { kDecModeSplit = 0u, kDecModeClassic = 1u };
+constexpr uint32_t kDecListShare = 48u;       // of all group parts of the launch (three per group)
+constexpr uint32_t kDecClassicLaunches = 64u;
 __device__ __forceinline__ void declist_push(const DecList& L, uint32_t fidx, uint32_t grp, uint32_t part) {
   // called by the lanes of a (possibly divergent) branch with wave-uniform arguments: the first active lane appends
   const unsigned long long m = __ballot(1);
@@ -1100,7 +1120,10 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode(const F
                                                          const QTab* __restrict__ lut,
                                                          const uint32_t* __restrict__ blkoff,
                                                          uint8_t* __restrict__ outbuf,
-                                                         const uint8_t* __restrict__ prev) {
+                                                         const uint8_t* __restrict__ prev,
+                                                         const uint32_t* __restrict__ only_in_mode) {
+  // (batches: the plan's decode policy — rtj_decode_chroma.h, DecPolicy — says whether this form or k_decode_split runs)
+  if (only_in_mode && *only_in_mode != kDecModeClassic) return;
   __shared__ __attribute__((aligned(16))) uint32_t s_lds[kDecLdsWords];
   const uint32_t slots = kRot ? gridDim.x : gridDim.x / 3u;
   const uint32_t slot = kRot ? blockIdx.x : blockIdx.x / 3u, part0 = kRot ? 0u : blockIdx.x - slot * 3u;

@@ -679,7 +679,8 @@ __global__ __launch_bounds__(64) void k_spec_repair(const FrameDev* __restrict__
 // two lost launches in a row pause the speculation for kSpecPauseLaunches launches, during which both walkers
 // and k_spec_verify return at once and this kernel puts every packet on the exact kernels' list.
 __global__ __launch_bounds__(256) void k_spec_policy(uint32_t n, uint32_t walkers, uint32_t* __restrict__ todo_cnt,
-                                                      const uint32_t* __restrict__ nfix, uint32_t* __restrict__ state) {
+                                                      const uint32_t* __restrict__ nfix, uint32_t* __restrict__ state,
+                                                      const uint32_t serial_min) {
   const uint32_t pause = state[kSpecStPause];
   if (pause) {
     for (uint32_t i = threadIdx.x; i < n; i += 256) todo_cnt[1 + i] = i;
@@ -713,6 +714,16 @@ __global__ __launch_bounds__(256) void k_spec_policy(uint32_t n, uint32_t walker
         state[kSpecStQuiet] = 0u;
       }
     }
+  }
+  // Who indexes the packets on the list: from serial_min packets on the serial walker (k_index_walk_todo, one wave per
+  // packet — enough of them in flight to beat the chunk-parallel kernels, whose work grows with the bytes), else the
+  // exact kernels.  The walker's count lives behind the list.
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t cnt = todo_cnt[0];
+    const bool serial = serial_min != 0u && cnt >= serial_min;
+    todo_cnt[1 + n] = serial ? cnt : 0u;
+    if (serial) todo_cnt[0] = 0u;
   }
 }
 

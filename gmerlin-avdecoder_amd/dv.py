@@ -8,7 +8,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 FRAME_BYTES, PICTURE_BYTES, W, H, CW = 120000, 720 * 480 * 3 // 2, 720, 480, 180
 EXPORTS = ["mi_dv_device_count", "mi_dv_create", "mi_dv_destroy", "mi_dv_last_error", "mi_dv_dev_alloc", "mi_dv_dev_free",
-           "mi_dv_h2d", "mi_dv_d2h", "mi_dv_sync", "mi_dv_decode_batch", "mi_dv_last_kernel_ms", "mi_dv_decode_frame",
+           "mi_dv_h2d", "mi_dv_d2h", "mi_dv_sync", "mi_dv_decode_batch", "mi_dv_kernel_times", "mi_dv_decode_frame",
            "mi_dv_copy_tables"]
 _LIB = None
 u8p = C.POINTER(C.c_uint8)
@@ -46,7 +46,7 @@ def load():
     L.mi_dv_d2h.argtypes = [vp, vp, vp, C.c_size_t]
     L.mi_dv_sync.argtypes = [vp]
     L.mi_dv_decode_batch.argtypes = [vp, vp, C.c_int, vp]
-    L.mi_dv_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.mi_dv_kernel_times.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     L.mi_dv_decode_frame.argtypes = [vp, u8p, C.c_size_t, C.POINTER(u8p), C.POINTER(C.c_int)]
     L.mi_dv_copy_tables.argtypes = [vp, C.c_size_t]
     L.mi_dv_copy_tables.restype = C.c_size_t
@@ -98,10 +98,11 @@ class MiDv:
     def decode_batch(self, d_frames, n, d_pics):
         self._chk(self.L.mi_dv_decode_batch(self.c, d_frames, n, d_pics))
 
-    def kernel_ms(self):
-        ms = C.c_float()
-        self._chk(self.L.mi_dv_last_kernel_ms(self.c, C.byref(ms)))
-        return ms.value
+    def kernel_times(self):
+        """(total milliseconds, launches) of k_dv_decode since the last call"""
+        ms, n = C.c_float(), C.c_int()
+        self._chk(self.L.mi_dv_kernel_times(self.c, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def decode_frames(self, frames):
         """host frames (n x 120000 uint8) -> host pictures (n x 518400), through the batch path"""

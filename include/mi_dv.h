@@ -45,9 +45,9 @@ int mi_dv_sync(mi_dv_ctx *c);
  * d_pics 8-byte aligned).  Queued on the instance's stream; pair with mi_dv_sync.  Any 120,000 bytes decode to
  * something (damaged frames are not detected, as in the oracle). */
 int mi_dv_decode_batch(mi_dv_ctx *c, const void *d_frames, int n, void *d_pics);
-/* the time the kernel of the last mi_dv_decode_batch took, in milliseconds (HIP events on the instance's stream;
- * synchronises) */
-int mi_dv_last_kernel_ms(mi_dv_ctx *c, float *ms);
+/* Device time of k_dv_decode: every mi_dv_decode_batch brackets its launch with HIP events on the instance's stream;
+ * this sums them over the launches since the last call (synchronises, then forgets them). */
+int mi_dv_kernel_times(mi_dv_ctx *c, float *total_ms, int *launches);
 
 /* One frame from host memory into the caller's planes (Y, Cb, Cr) with the caller's strides — what a
  * bgav_video_decoder_t::decode does with a packet and a gavl_video_frame_t.  Synchronous.  Checks that the frame

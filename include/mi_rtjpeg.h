@@ -169,6 +169,12 @@ int mi_rtj_plan_spec_stats(mi_rtj_plan *plan, int *proven, long long *walkers, l
  * before its chunk (the short or the long form; 0: the speculative index is not used for this plan),
  * *paused_launches = decodes left that go straight to the exact kernels.  Synchronises the instance's stream. */
 int mi_rtj_plan_spec_lead(mi_rtj_plan *plan, int *lead_bytes, int *paused_launches);
+/* Which form of the transform kernel the plan's device-side policy has chosen for the NEXT batch decode: *form = 0
+ * k_decode_split (luma waves + chroma waves that pool three groups' busy blocks), 1 k_decode<true, false> (a wave takes
+ * the three parts of its groups; what noisy content gets), -1 no batch launch yet / not a batch plan;
+ * *classic_launches_left = decodes left before the split form is tried again; *parts_listed = group parts the last
+ * decode left to k_decode_list.  Synchronises the instance's stream. */
+int mi_rtj_plan_decode_form(mi_rtj_plan *plan, int *form, int *classic_launches_left, long long *parts_listed);
 /* Test hook: copy the plan's block-start index (relative to each packet's first data byte,
  * nblocks+1 entries per frame, frames back to back) to the host after a decode. */
 int mi_rtj_plan_read_index(mi_rtj_plan *plan, uint32_t *dst, size_t max_entries);

@@ -339,7 +339,7 @@ static void decode_ac(blk_t *k, bitbuf *b) {
   }
 }
 
-static void decode_segment(const uint8_t *dif, int seq, int slot, uint8_t *pic) {
+static void decode_segment(const uint8_t *dif, int seq, int slot, uint8_t *pic, int16_t (*coefs)[64]) {
   blk_t blk[5][6];
   bitbuf mbuf[5], vbuf;
   vbuf.n = vbuf.rd = 0;
@@ -374,6 +374,11 @@ static void decode_segment(const uint8_t *dif, int seq, int slot, uint8_t *pic) 
   for (int m = 0; m < 5; m++) /* pass 3 */
     for (int j = 0; j < 6; j++)
       if (blk[m][j].pos < 64 && vbuf.rd < vbuf.n) decode_ac(&blk[m][j], &vbuf);
+  if (coefs) {
+    for (int m = 0; m < 5; m++)
+      for (int j = 0; j < 6; j++) memcpy(coefs[6 * m + j], blk[m][j].coef, sizeof blk[m][j].coef);
+    return;
+  }
   for (int m = 0; m < 5; m++) {
     int x, y;
     dvo_mb_place(seq, slot, m, &x, &y);
@@ -394,7 +399,11 @@ static void decode_segment(const uint8_t *dif, int seq, int slot, uint8_t *pic) 
 void dvo_decode_frame(const uint8_t *dif, uint8_t *pic) {
   init_once();
   for (int seq = 0; seq < 10; seq++)
-    for (int slot = 0; slot < 27; slot++) decode_segment(dif, seq, slot, pic);
+    for (int slot = 0; slot < 27; slot++) decode_segment(dif, seq, slot, pic, NULL);
+}
+void dvo_segment_coefs(const uint8_t *dif, int seq, int slot, int16_t coefs[30][64]) {
+  init_once();
+  decode_segment(dif, seq, slot, NULL, coefs);
 }
 
 /* ---------------- encoder (makes the test streams) ---------------- */

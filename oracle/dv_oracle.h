@@ -34,6 +34,10 @@ void dvo_encode_frame(const uint8_t *pic, uint8_t *dif, int flags);
 /* one DIF frame (any 120,000 bytes) -> one picture */
 void dvo_decode_frame(const uint8_t *dif, uint8_t *pic);
 
+/* the reconstructed coefficients (natural order, the level shift on DC) of the 30 blocks of one video segment after the
+ * three passes */
+void dvo_segment_coefs(const uint8_t *dif, int seq, int slot, int16_t coefs[30][64]);
+
 /* pieces, for known-answer tests */
 /* the 64 reconstruction multipliers (scan order, 14 fractional bits) of a transform mode: 0 = 8-8, 1 = 2-4-8 */
 void dvo_qbase(int mode, int32_t out[64]);

@@ -23,6 +23,8 @@
  *   ptsjump=N:D   packets N.. carry time stamps D later: a forward jump that is a property of the stream (an empty
  *                 edit, a fragment gap), nothing is skipped
  *   noci=1        the stream has no compression info (s->ci == NULL)
+ *   fourcc=XXXX   the stream's fourcc (default RTJ0; "dvc " with packets of 120,000-byte DIF frames plays DV through
+ *                 csrc/video_dv_mi355x.c in the harness built with -DMI_HARNESS_DV)
  *
  * skipto= follows the library: streams whose compression info says GAVL_COMPRESSION_HAS_P_FRAMES go to the decoder's
  * .skipto (or decode-and-drop), the others have their packets skipped at the source; skippkts= forces the latter.
@@ -94,6 +96,7 @@ gavl_video_frame_t *gavl_video_frame_create(const gavl_video_format_t *format) {
 }
 void gavl_video_frame_null(gavl_video_frame_t *f) { memset(f->planes, 0, sizeof f->planes); }
 void gavl_video_frame_destroy(gavl_video_frame_t *f) { free(f); }
+const gavl_video_format_t *gavl_stream_get_video_format(const gavl_dictionary_t *stream) { return stream ? stream->vfmt : NULL; }
 void gavl_log(int level, const char *domain, const char *fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -154,6 +157,7 @@ static void *play(void *arg) {
   gavl_dictionary_t meta, info;
   memset(&meta, 0, sizeof meta);
   memset(&info, 0, sizeof info);
+  info.vfmt = &fmt; /* the demultiplexer knows the picture size before a decoder is chosen */
   gavl_compression_info_t ci = {0}; /* RTJ0 in a QuickTime file whose samples are all sync samples: intra-only
                                        (lib/demux_quicktime.c:1522-1525) until the decoder says otherwise */
   bgav_stream_t s = {0};
@@ -177,7 +181,8 @@ static void *play(void *arg) {
   /* the caller's frame: gavl aligns strides; use a deliberately odd pitch */
   gavl_video_frame_t f;
   memset(&f, 0, sizeof f);
-  const int cw = (iw + 1) / 2, ch = (ih + 1) / 2;
+  /* chroma planes by the pixel format the decoder announced: 4:2:0 (RTjpeg) or 4:1:1 (DV 525/60) */
+  const int cw = fmt.pixelformat == GAVL_YUV_411_P ? iw / 4 : (iw + 1) / 2, ch = fmt.pixelformat == GAVL_YUV_411_P ? ih : (ih + 1) / 2;
   f.strides[0] = ((iw + 63) & ~63) + 64;
   f.strides[1] = f.strides[2] = ((cw + 63) & ~63) + 64;
   f.planes[0] = malloc((size_t)f.strides[0] * ih);
@@ -264,6 +269,7 @@ int main(int argc, char **argv) {
   if (argc < 5) return fprintf(stderr, "usage: %s packets.bin|movie.mov w h out.bin [skip_every]  (w h 0 0: from the movie)\n", argv[0]), 1;
   int iw = atoi(argv[2]), ih = atoi(argv[3]);
   int streams = 1, jump_at = -1;
+  uint32_t fourcc_arg = 0;
   long long jump_by = 0;
   play_t cfg = {0};
   gavl_dictionary_t opt;
@@ -283,6 +289,11 @@ int main(int argc, char **argv) {
     if (sscanf(argv[i], "streams=%d", &streams) == 1) continue;
     if (sscanf(argv[i], "ptsjump=%d:%lld", &jump_at, &jump_by) == 2) continue;
     if (sscanf(argv[i], "noci=%d", &cfg.noci) == 1) continue;
+    if (strncmp(argv[i], "fourcc=", 7) == 0 && strlen(argv[i]) == 11) {
+      const unsigned char *c4 = (const unsigned char *)argv[i] + 7;
+      fourcc_arg = ((uint32_t)c4[0] << 24) | ((uint32_t)c4[1] << 16) | ((uint32_t)c4[2] << 8) | c4[3];
+      continue;
+    }
     if (sscanf(argv[i], "opt=%31[^:]:%d", key, &val) == 2 && opt.n_ints < MI_COMPAT_DICT_INTS) {
       snprintf(opt.ints[opt.n_ints].key, sizeof opt.ints[0].key, "%s", key);
       opt.ints[opt.n_ints++].val = val;
@@ -318,7 +329,11 @@ int main(int argc, char **argv) {
     if (jump_at >= 0 && i >= jump_at) q.pkts[i].pts += jump_by;
   if (streams < 1 || streams > 16 || (streams > 1 && !cfg.bench)) return fprintf(stderr, "streams=1..16, more than one only with bench=1\n"), 1;
 
+  if (fourcc_arg) fourcc = fourcc_arg;
   /* bgav_codecs_init -> bgav_init_video_decoders_rtjpeg (lib/codecs.c:176) */
+#ifdef MI_HARNESS_DV
+  bgav_init_video_decoders_dv_mi355x(); /* in front of the library's other decoders */
+#endif
   bgav_init_video_decoders_rtjpeg();
 
   cfg.pkts = q.pkts;

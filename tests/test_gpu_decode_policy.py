@@ -1,0 +1,109 @@
+"""The batch launches' decode policy (csrc/rtj_decode_kernels.h, kDecMode*): k_decode_split — luma waves and chroma waves
+that pool three groups' busy blocks (csrc/rtj_decode_chroma.h) — while next to nothing is left to k_decode_list,
+k_decode<true, false> for 64 launches after a launch whose chroma the pooling waves did not cover.  Pictures are the
+oracle's whatever form runs, through the change of form and back."""
+import numpy as np
+import pytest
+
+import rtjlib as R
+import test_gpu_parity as T
+from pkg import P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def dev(monkeypatch):
+    monkeypatch.setenv("MI_RTJ_ROTATE", "1")  # the batch launch shape for small batches too
+    d = P.MiRtj()
+    yield d
+    d.close()
+
+
+def run(dev, pkts, w, h, launches):
+    fsz = T.frame_bytes(w, h)
+    want = []
+    for p in pkts:
+        o = np.zeros(fsz, np.uint8)
+        R.OracleDecoder().decode(p, o)
+        want.append(o)
+    d_stream, po, pl, hdrs = dev.upload_packets(pkts, align=1)
+    d_out = dev.alloc(fsz * len(pkts))
+    plan = dev.plan(hdrs, po, pl, np.arange(len(pkts), dtype=np.uint64) * np.uint64(fsz))
+    forms = []
+    for k in range(launches):
+        dev.memset(d_out, 0, fsz * len(pkts))
+        plan.decode(d_stream, d_out)
+        dev.sync()
+        forms.append(plan.decode_form())
+        if k < 3 or k >= launches - 3 or k % 16 == 0:
+            for i in range(len(pkts)):
+                assert np.array_equal(dev.d2h(d_out, fsz, offset=i * fsz), want[i]), (k, i)
+    plan.close()
+    dev.free(d_stream)
+    dev.free(d_out)
+    return forms
+
+
+def test_clean_content_stays_with_the_split_form(dev):
+    w, h = 640, 368
+    pkts = [R.OracleEncoder(w, h, Q).encode(R.synth_frame(w, h, i, seed=5, amp=a)) for i, (Q, a) in enumerate([(255, 8), (255, 0), (128, 8), (64, 6)] * 2)]
+    forms = run(dev, pkts, w, h, 4)
+    assert all(f[0] == 0 for f in forms), forms
+    assert forms[-1][2] <= 2  # next to nothing for k_decode_list
+
+
+def test_noisy_content_moves_to_the_classic_form_and_comes_back(dev):
+    w, h = 640, 368
+    pkts = [R.OracleEncoder(w, h, 255).encode(R.synth_frame(w, h, i, seed=6, amp=48)) for i in range(6)]
+    forms = run(dev, pkts, w, h, 68)
+    assert forms[0][0] == 1 and forms[0][2] > 0, forms[0]     # the first launch listed most chroma parts: classic next
+    assert all(f[0] == 1 and f[2] == 0 for f in forms[1:64]), forms[1:5]  # 64 classic launches, nothing listed
+    assert forms[64][0] == 0, forms[62:66]                     # then the split form is tried again ...
+    assert forms[65][0] == 1, forms[62:67]                     # ... and given up again on this content
+
+
+def test_forced_forms(dev, monkeypatch):
+    w, h = 320, 240
+    pkts = [R.OracleEncoder(w, h, 255).encode(R.synth_frame(w, h, i, seed=7, amp=a)) for i, a in enumerate([4, 60, 8, 30])]
+    for v in ("0", "1"):
+        monkeypatch.setenv("MI_RTJ_SPLIT", v)
+        forms = run(dev, pkts, w, h, 3)
+        assert all(f[0] == 1 - int(v) for f in forms), (v, forms)
+
+
+def test_long_to_do_lists_go_to_the_serial_walker(monkeypatch):
+    """packets the speculative index refuses (noisy content) are indexed by the serial walker, one wave
+    per packet, when there are many of them (k_spec_policy; MI_RTJ_SERIAL_MIN lowers "many" for this small batch), by the
+    exact kernels otherwise — the same index and the same pictures either way, launch after launch (the policy moves
+    through its leads and pauses the speculation on this content)"""
+    monkeypatch.setenv("MI_RTJ_SPEC", "2")  # speculate whatever the batch size, with the policy
+    w, h = 320, 240
+    pkts = [R.OracleEncoder(w, h, 255).encode(R.synth_frame(w, h, i, seed=8, amp=64 if i % 3 else 6)) for i in range(24)]
+    fsz = T.frame_bytes(w, h)
+    want = []
+    for p in pkts:
+        o = np.zeros(fsz, np.uint8)
+        R.OracleDecoder().decode(p, o)
+        want.append(o)
+    nblk = (w // 16) * (h // 16) * 6
+    for serial_min in ("4", "0"):
+        monkeypatch.setenv("MI_RTJ_SERIAL_MIN", serial_min)
+        dev = P.MiRtj()
+        d_stream, po, pl, hdrs = dev.upload_packets(pkts, align=1)
+        d_out = dev.alloc(fsz * len(pkts))
+        plan = dev.plan(hdrs, po, pl, np.arange(len(pkts), dtype=np.uint64) * np.uint64(fsz))
+        for k in range(8):
+            dev.memset(d_out, 0, fsz * len(pkts))
+            plan.decode(d_stream, d_out)
+            dev.sync()
+            idx = plan.read_index()
+            at = 0
+            for i, p in enumerate(pkts):
+                assert np.array_equal(idx[at:at + nblk + 1], R.OracleDecoder().block_offsets(p) - 12), (serial_min, k, i)
+                at += nblk + 1
+                assert np.array_equal(dev.d2h(d_out, fsz, offset=i * fsz), want[i]), (serial_min, k, i)
+        plan.close()
+        dev.free(d_stream)
+        dev.free(d_out)
+        dev.close()

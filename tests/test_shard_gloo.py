@@ -60,3 +60,41 @@ def test_two_rank_reduction_over_gloo(tmp_path):
     line = [l for l in outs[0][0].splitlines() if l.startswith("RESULT")][0].split()
     assert int(line[1]) == 64 and int(line[2]) == 64 * 1920 * 1088 and int(line[3]) == 1
     assert abs(float(line[4]) - 1.5) < 1e-9  # MAX over ranks, not the mean
+
+
+def test_rank_to_numa_node_mapping(tmp_path):
+    """a rank runs on the cores of its GPU's NUMA node.  A made-up sysfs tree: four AMD GPUs on two
+    nodes (enumerated by PCI address, whatever the card numbers), one card of another vendor, connector entries."""
+    import importlib
+    shard = importlib.import_module("gmerlin-avdecoder_amd.shard")
+    sysfs = tmp_path / "sys"
+
+    def card(name, pci, vendor, node):
+        real = sysfs / "devices" / "pci0000:00" / pci
+        real.mkdir(parents=True)
+        (real / "vendor").write_text(vendor + "\n")
+        if node is not None:
+            (real / "numa_node").write_text(f"{node}\n")
+        d = sysfs / "class" / "drm" / name
+        d.mkdir(parents=True)
+        (d / "device").symlink_to(real)
+
+    card("card3", "0000:05:00.0", "0x1002", 0)
+    card("card0", "0000:85:00.0", "0x1002", 1)
+    card("card1", "0000:25:00.0", "0x1002", 0)
+    card("card2", "0000:a5:00.0", "0x1002", 1)
+    card("card4", "0000:01:00.0", "0x10de", 0)
+    (sysfs / "class" / "drm" / "card0-DP-1").mkdir()
+    for node, cpus in ((0, "0-3,16-19"), (1, "4-7,20-23")):
+        nd = sysfs / "devices" / "system" / "node" / f"node{node}"
+        nd.mkdir(parents=True)
+        (nd / "cpulist").write_text(cpus + "\n")
+    assert shard.gpu_numa_nodes(str(sysfs)) == [("0000:05:00.0", 0), ("0000:25:00.0", 0), ("0000:85:00.0", 1), ("0000:a5:00.0", 1)]
+    assert shard.cpus_for_gpu(0, str(sysfs)) == [0, 1, 2, 3, 16, 17, 18, 19]
+    assert shard.cpus_for_gpu(3, str(sysfs)) == [4, 5, 6, 7, 20, 21, 22, 23]
+    assert shard.cpus_for_gpu(2, str(sysfs), allowed={5, 6, 99}) == [5, 6]
+    assert shard.cpus_for_gpu(2, str(sysfs), allowed={0, 1}) is None   # nothing of that node may be used: hands off
+    assert shard.cpus_for_gpu(7, str(sysfs)) is None
+    assert shard.parse_cpulist("0-2,5, 9-9") == {0, 1, 2, 5, 9}
+    r = shard.bind_rank_to_gpu_node(9, str(sysfs))
+    assert r["bound"] is False
