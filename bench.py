@@ -76,6 +76,9 @@ def parse():
     ap.add_argument("--quality", type=int, default=255)
     ap.add_argument("--amp", type=int, default=8, help="noise amplitude of the synthetic content")
     ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--content", choices=["hash", "lcg"], default="hash",
+                    help="noise of the synthetic pictures: hash = k_synth's counter-based hash (the default since round 1), "
+                         "lcg = SURVEY 8d / BASELINE.md section 2's linear congruential sequence (k_synth_lcg)")
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="budget of each CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU legs (and with them the parity check)")
     ap.add_argument("--no-stress", action="store_true", help="skip the short second measurement on noisy content")
@@ -248,9 +251,12 @@ def run_frames(a, dev, rank, n, amp, steps, warmup, barrier, sync_all, timed_unp
     import numpy as np
     w, h, Q = a.width, a.height, a.quality
     fsz = w * h * 3 // 2
-    d_fr = dev.synth(w, h, rank * n, n, seed=a.seed, amp=amp)
-    d_st, po, pl = dev.encode(w, h, Q, n, d_fr)
+    d_fr = (dev.synth_lcg if a.content == "lcg" else dev.synth)(w, h, rank * n, n, seed=a.seed, amp=amp)
     dev.sync()
+    t_enc = time.perf_counter()
+    d_st, po, pl = dev.encode(w, h, Q, n, d_fr)  # the GPU encoder: synchronous, frames and stream resident in HBM
+    dev.sync()
+    t_enc = time.perf_counter() - t_enc
     dev.free(d_fr)
     hdr0 = dev.d2h(d_st, 12, offset=int(po[0]))
     # MI_RTJ_BENCH_PAD (experiments only): bytes left free behind every picture of the output buffer
@@ -284,7 +290,7 @@ def run_frames(a, dev, rank, n, amp, steps, warmup, barrier, sync_all, timed_unp
     step_ms = plan.step_times()
     plan.profile(False)
     return dict(plan=plan, info=info, dt=dt, ktimes=ktimes, launches=launches, step_ms=step_ms, d_st=d_st, d_out=d_out,
-                po=po, pl=pl, fsz=fsz, n=n)
+                po=po, pl=pl, fsz=fsz, n=n, t_enc=t_enc)
 
 
 def main():
@@ -412,10 +418,15 @@ def main():
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "i32", "data": "synthetic",
             "config": {"workload": f"RTjpeg {w}x{h} YUV420 Q={Q} intra-only, {n} distinct frames/GPU resident in HBM "
-                                   f"(BASELINE configs[1]); content: gradient + noise amp {a.amp}, seed {a.seed}, from the "
-                                   f"device generator k_synth (= tests/rtjlib.py synth_frame: hash-counter noise, gradient "
-                                   f"wrapped mod w+h) — NOT SURVEY 8d's LCG generator; packets within 1 % of its size "
-                                   f"(588 vs 583 kB), digests pinned to the reference encoder on the same frames",
+                                   f"(BASELINE configs[1]); content: gradient + noise amp {a.amp}, seed {a.seed}, " +
+                                   ("SURVEY 8d's generator: the noise of ONE linear congruential sequence (s*1664525+1013904223, "
+                                    "s>>8) over all frames, device generator k_synth_lcg = tests/rtjlib.py synth_frame_lcg; frames, "
+                                    "packets and planes pinned to the reference's own lib/RTjpeg.c (tests/golden/lcg_golden.json)"
+                                    if a.content == "lcg" else
+                                    "device generator k_synth (= tests/rtjlib.py synth_frame: hash-counter noise, gradient "
+                                    "wrapped mod w+h); `--content lcg` runs SURVEY 8d's LCG noise instead (same gradient, "
+                                    "packets within 1 % of the same size), digests pinned to the reference encoder on the same frames"),
+                       "content": a.content,
                        "frames_per_gpu": n, "avg_packet_bytes": int(info["bytes_in"] // n),
                        "sharding": "frames, no data-path collective"},
             "mpixels_per_s": round(fps * w * h / 1e6, 1),
@@ -440,6 +451,12 @@ def main():
                                       chunks_repaired=getattr(plan, "repaired", 0),
                                       walker_lead_bytes=plan.spec_lead()[0]),  # what the policy chose for the next launch
             "path_gbs": round(alg_bytes * a.steps / dt / 1e9, 2),
+            "encoder": {"frames_per_s": round(n / r["t_enc"], 1), "seconds": round(r["t_enc"], 4),
+                        "gbs": round((info["bytes_in"] + info["bytes_out"]) / r["t_enc"] / 1e9, 1),
+                        "frac_of_hbm_peak": round((info["bytes_in"] + info["bytes_out"]) / r["t_enc"] / 1e9 / HBM_PEAK_GBS, 4),
+                        "note": "mi_rtj_encode_frames making this run's packets (intra, byte-exact with the reference encoder: "
+                                "tests/test_gpu_parity.py): pictures read once + packets written once over the wall time of the "
+                                "call, host side included (one synchronisation at the end); not part of `value`"},
             "host_binding": numa,  # rank 0's: cores of its GPU's NUMA node (gmerlin-avdecoder_amd/shard.py)
         }
         # the vector-issue roof of k_decode: instructions per launch from the PMC profile of these sources
@@ -534,7 +551,7 @@ def main():
     # SURVEY.md section 8d's stress variant (noise +-64: 2.3 MB packets, nothing for the speculative index to lock on)
     # as a second, short, clearly labelled measurement; never part of `value`
     if world == 1 and rank == 0 and not a.no_stress and a.amp != 64:
-        ns_frames = min(n, 1024)
+        ns_frames = n  # the headline launch size: its plan runs its kernels back to back, so kernels_ms are kernel costs
         # five warm-up launches: the plan's policy needs three to give the speculation up on this content (short lead lost,
         # long lead lost twice: k_spec_policy), after which the walkers return at once for 64 launches — the timed steps
         # are the steady state (round 2 timed one of the three and reported 93.6 K)
@@ -544,8 +561,12 @@ def main():
                                "kernels_ms": {k: round(v / max(s["launches"], 1), 4) for k, v in s["ktimes"].items() if v > 0},
                                "packets_proven": s["plan"].spec_stats()[0],
                                "speculation_paused_launches_left": s["plan"].spec_lead()[1],
+                               "index": "serial walker (k_index_walk_todo, one wave per packet)" if ns_frames >= 4096 else "exact kernels",
+                               "decode_form": s["plan"].decode_form()[0],
                                "note": "same code, noise amplitude 64 (SURVEY 8d stress variant), 5 timed steps after 5 warm-up "
-                                       "launches: steady state, the speculative index paused by its policy, the exact index alone"}
+                                       "launches: steady state — the speculative index paused by its policy, the packets indexed by the "
+                                       "serial walker (launches of 4096 packets and more: its time is in the k_index_summarize slot) or "
+                                       "the exact kernels, k_decode in its classic form (decode_form 1)"}
         s["plan"].close()
         dev.free(s["d_st"])
         dev.free(s["d_out"])

@@ -27,7 +27,7 @@ EXPORTS = ["mi_rtj_device_count", "mi_rtj_create", "mi_rtj_destroy", "mi_rtj_las
            "mi_rtj_get_state", "mi_rtj_dev_alloc", "mi_rtj_dev_free", "mi_rtj_h2d", "mi_rtj_d2h",
            "mi_rtj_dev_memset", "mi_rtj_sync", "mi_rtj_plan_create", "mi_rtj_plan_destroy",
            "mi_rtj_plan_decode", "mi_rtj_plan_info", "mi_rtj_plan_profile", "mi_rtj_plan_times",
-           "mi_rtj_plan_read_index", "mi_rtj_synth_frames", "mi_rtj_encode_bound", "mi_rtj_encode_frames",
+           "mi_rtj_plan_read_index", "mi_rtj_synth_frames", "mi_rtj_synth_frames_lcg", "mi_rtj_encode_bound", "mi_rtj_encode_frames",
            "mi_rtj_get_tables", "mi_rtj_yuv420_to_rgb", "mi_rtj_encode_stream", "mi_rtj_decode_nocopy",
            "mi_rtj_copy_ceiling", "mi_rtj_plan_spec_stats", "mi_rtj_plan_spec_lead", "mi_rtj_plan_decode_form",
            "mi_rtj_plan_step_times", "mi_rtj_pipe_create", "mi_rtj_pipe_destroy", "mi_rtj_pipe_room",
@@ -376,6 +376,14 @@ class MiRtj:
         fsz = w * h * 3 // 2
         d = dptr if dptr is not None else self.alloc(fsz * n)
         self._chk(self.L.mi_rtj_synth_frames(self.h, w, h, first, n, seed, amp, d))
+        return d
+
+    def synth_lcg(self, w, h, first, n, seed=12345, amp=8, dptr=None):
+        """SURVEY 8d's generator: LCG noise, one sequence over all frames (see include/mi_rtjpeg.h)"""
+        fsz = w * h * 3 // 2
+        d = dptr if dptr is not None else self.alloc(fsz * n)
+        self.L.mi_rtj_synth_frames_lcg.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_void_p]
+        self._chk(self.L.mi_rtj_synth_frames_lcg(self.h, w, h, first, n, seed, amp, d))
         return d
 
     def encode(self, w, h, Q, n, d_frames, align=64, key_rate=0, lmask=0, cmask=0):

@@ -1450,7 +1450,24 @@ mi_rtj_pipe* mi_rtj_pipe_create(mi_rtj_ctx* c, int depth, int max_w, int max_h) 
     }
     if (q->group > 1) q->grp_fsz = (size_t)max_w * max_h * 3 / 2;
   }
-  bool ok = hipStreamCreateWithFlags(&q->s_in, hipStreamNonBlocking) == hipSuccess;
+  // The runtime multiplexes the streams of a process onto a few hardware queues PER PRIORITY (four by default,
+  // GPU_MAX_HW_QUEUES): with every stream at the default priority two sessions' eight streams shared four queues and one
+  // session's copy in waited behind the other's copy out (two sessions then aggregated LESS than one).
+  // The copy streams of a session are therefore created at the two other priorities the device offers — packets in at
+  // the highest, pictures out at the lowest — which puts them into queue pools of their own: kernels, copies in and
+  // copies out of several sessions no longer meet in one queue, and the application need not set anything.  (For copies
+  // the priority itself changes nothing: they run on the copy engines.)  MI_RTJ_STREAM_PRIO=0: all default (A/B).
+  int prio_lo = 0, prio_hi = 0;  // numerically: lowest priority = largest value
+  {
+    const char* sp = getenv("MI_RTJ_STREAM_PRIO");
+    if ((!sp || atoi(sp) != 0) && hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) prio_lo = prio_hi = 0;
+    if (sp && atoi(sp) == 0) prio_lo = prio_hi = 0;
+  }
+  auto make_stream = [&](hipStream_t* st, int prio) {
+    return (prio_lo != prio_hi ? hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio)
+                               : hipStreamCreateWithFlags(st, hipStreamNonBlocking)) == hipSuccess;
+  };
+  bool ok = make_stream(&q->s_in, prio_hi);
   {
     // off unless asked for: with the index on a stream of its own a 1080p session ran at 6,600 pictures per second
     // instead of 12,000 (profiles/r03/e2e_ab.txt) — every packet then crosses streams twice more, and the runtime's
@@ -1458,7 +1475,7 @@ mi_rtj_pipe* mi_rtj_pipe_create(mi_rtj_ctx* c, int depth, int max_w, int max_h) 
     const char* ix = exp_env("MI_RTJ_IDX_STREAM");
     if (ix && atoi(ix) != 0) ok = ok && hipStreamCreateWithFlags(&q->s_idx, hipStreamNonBlocking) == hipSuccess;
   }
-  for (int i = 0; i < q->n_out; i++) ok = ok && hipStreamCreateWithFlags(&q->s_out[i], hipStreamNonBlocking) == hipSuccess;
+  for (int i = 0; i < q->n_out; i++) ok = ok && make_stream(&q->s_out[i], prio_lo);
   const char* mode = getenv("MI_RTJ_INDEX");
   const char* em = getenv("MI_RTJ_EMIT");
   for (auto& sl : q->slot) {
@@ -1856,6 +1873,15 @@ int mi_rtj_synth_frames(mi_rtj_ctx* c, int w, int h, int first, int n, uint32_t 
   return MI_RTJ_OK;
 }
 
+int mi_rtj_synth_frames_lcg(mi_rtj_ctx* c, int w, int h, int first, int n, uint32_t seed, int amp, void* d_frames) {
+  if (!c || !d_frames || w <= 0 || h <= 0 || (w & 15) || (h & 15) || n <= 0 || amp < 0 || first < 0)
+    return fail(c, MI_RTJ_ERR_ARG, "mi_rtj_synth_frames_lcg: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  hipLaunchKernelGGL(k_synth_lcg, dim3(4096), dim3(256), 0, c->stream, (uint8_t*)d_frames, w, h, first, n, seed, amp);
+  HIPCHK(c, hipGetLastError());
+  return MI_RTJ_OK;
+}
+
 size_t mi_rtj_encode_bound(int w, int h, int n, int align) {
   if (w <= 0 || h <= 0 || n <= 0 || align < 1) return 0;
   const size_t per = MI_RTJ_HEADER_SIZE + (size_t)(w / 16) * (h / 16) * 6 * 64;
@@ -1881,10 +1907,12 @@ int encode_impl(mi_rtj_ctx* c, int w, int h, int Q, int key_rate, int lmask, int
   HIPCHK(c, hipSetDevice(c->device));
   const uint32_t nblk = (uint32_t)(w / 16) * (h / 16) * 6;
   const size_t fsz = (size_t)w * h * 3 / 2;
-  const int chunk = inter ? 1 : 32;  // frames per pass: inter frames depend on each other, intra ones do not
+  // frames per pass: inter frames depend on each other, intra ones do not (256: 0.8 GB of block slots at 1080p)
+  const int chunk = inter ? 1 : (int)std::max<size_t>(1, std::min<size_t>(256, ((size_t)1 << 30) / ((size_t)nblk * 64)));
   uint8_t *slots = nullptr, *lens = nullptr;
   uint32_t *offs = nullptr, *fbytes = nullptr;
-  uint64_t* d_pktoff = nullptr;
+  uint64_t *d_pktoff = nullptr, *d_alloff = nullptr;
+  uint32_t* d_alllen = nullptr;
   int16_t* old = nullptr;
   int rc = MI_RTJ_OK;
   auto cleanup = [&]() {
@@ -1894,6 +1922,8 @@ int encode_impl(mi_rtj_ctx* c, int w, int h, int Q, int key_rate, int lmask, int
     if (offs) (void)hipFree(offs);
     if (fbytes) (void)hipFree(fbytes);
     if (d_pktoff) (void)hipFree(d_pktoff);
+    if (d_alloff) (void)hipFree(d_alloff);
+    if (d_alllen) (void)hipFree(d_alllen);
     if (old) (void)hipFree(old);
   };
 #define ENC_CHK(call)                                                                                         \
@@ -1911,32 +1941,37 @@ int encode_impl(mi_rtj_ctx* c, int w, int h, int Q, int key_rate, int lmask, int
   ENC_CHK(hipMalloc((void**)&fbytes, (size_t)chunk * 4));
   ENC_CHK(hipMalloc((void**)&d_pktoff, (size_t)chunk * 8));
   if (inter) ENC_CHK(hipMalloc((void**)&old, (size_t)nblk * 64 * sizeof(int16_t)));
-  std::vector<uint32_t> hb(chunk);
-  uint64_t cursor = 0;
+  // packet offsets and lengths of ALL frames stay on the device until the end: no host round trip between passes
+  ENC_CHK(hipMalloc((void**)&d_alloff, (size_t)n * 8 + 8));
+  ENC_CHK(hipMalloc((void**)&d_alllen, (size_t)n * 4));
+  uint64_t* const d_cursor = d_alloff + n;
+  ENC_CHK(hipMemsetAsync(d_cursor, 0, 8, c->stream));
   int key_count = 0;
   for (int f0 = 0; f0 < n; f0 += chunk) {
     const int m = n - f0 < chunk ? n - f0 : chunk;
     const size_t tot = (size_t)m * nblk;
     // RTjpeg_compress: the previous-block store is cleared whenever key_count is 0 (lib/RTjpeg.c:3504-3505)
     if (inter && key_count == 0) ENC_CHK(hipMemsetAsync(old, 0, (size_t)nblk * 64 * sizeof(int16_t), c->stream));
-    hipLaunchKernelGGL(k_encode_blocks, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
-                       (const uint8_t*)d_frames + (size_t)f0 * fsz, w, h, m, c->d_lut + Q, slots, lens, old, lmask, cmask);
-    hipLaunchKernelGGL(k_encode_scan, dim3(m), dim3(256), 0, c->stream, lens, nblk, offs, fbytes);
-    ENC_CHK(hipMemcpyAsync(hb.data(), fbytes, (size_t)m * 4, hipMemcpyDeviceToHost, c->stream));
-    ENC_CHK(hipStreamSynchronize(c->stream));
-    for (int i = 0; i < m; i++) {
-      cursor = (cursor + align - 1) / align * align;
-      pkt_offset[f0 + i] = cursor;
-      pkt_len[f0 + i] = hb[i] + MI_RTJ_HEADER_SIZE;
-      cursor += pkt_len[f0 + i];
+    if (inter) {
+      hipLaunchKernelGGL(k_encode_blocks, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
+                         (const uint8_t*)d_frames + (size_t)f0 * fsz, w, h, m, c->d_lut + Q, slots, lens, old, lmask, cmask);
+    } else {  // intra: a wave per 64 horizontally adjacent blocks (rtj_encode_kernels.h)
+      const unsigned groups = (nblk / 6u + (unsigned)kMbPerGroup - 1u) / (unsigned)kMbPerGroup;
+      hipLaunchKernelGGL(k_encode_wave, dim3(3u * groups, (unsigned)m), dim3(64), 0, c->stream,
+                         (const uint8_t*)d_frames + (size_t)f0 * fsz, w, h, c->d_lut + Q, slots, lens);
     }
-    ENC_CHK(hipMemcpyAsync(d_pktoff, pkt_offset + f0, (size_t)m * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_encode_scan, dim3(m), dim3(256), 0, c->stream, lens, nblk, offs, fbytes);
+    hipLaunchKernelGGL(k_encode_place, dim3(1), dim3(256), 0, c->stream, fbytes, m, (uint32_t)align, d_cursor, d_alloff + f0,
+                       d_alllen + f0, d_pktoff);
     hipLaunchKernelGGL(k_encode_pack, dim3((nblk + 255) / 256, m), dim3(256), 0, c->stream, slots, lens, offs,
                        d_pktoff, fbytes, nblk, w, h, Q, inter ? key_count : 0, (uint8_t*)d_stream);
     ENC_CHK(hipGetLastError());
-    ENC_CHK(hipStreamSynchronize(c->stream));
     if (inter && ++key_count > key_rate) key_count = 0;  // lib/RTjpeg.c:3512-3514
   }
+  // one copy of every packet's place and size at the end (the kernels of all passes are queued by now)
+  ENC_CHK(hipMemcpyAsync(pkt_offset, d_alloff, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+  ENC_CHK(hipMemcpyAsync(pkt_len, d_alllen, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  ENC_CHK(hipStreamSynchronize(c->stream));
 #undef ENC_CHK
   cleanup();
   return MI_RTJ_OK;

@@ -47,6 +47,50 @@ __global__ void k_synth(uint8_t* __restrict__ frames, int w, int h, int first_fr
   }
 }
 
+// The same pictures with the noise of SURVEY.md section 8d / BASELINE.md section 2: ONE linear congruential sequence
+// s <- s * 1664525 + 1013904223 (mod 2^32) from `seed`, one draw per sample in the order frame 0 Y (row major), U, V,
+// frame 1 ..., noise = ((s >> 8) mod (2a + 1)) - a with a = amp (luma) / amp / 2 (chroma).  A thread jumps to the
+// state of its first sample — s_k = A^k s_0 + C (A^k - 1) / (A - 1), by squaring: 32 steps — and draws kLcgRun samples in
+// a row.  (The gradient wraps mod w + h as in k_synth: BASELINE.md's unwrapped formula saturates after a few hundred
+// frames.)
+constexpr uint32_t kLcgA = 1664525u, kLcgC = 1013904223u;
+constexpr int kLcgRun = 256;
+__device__ __forceinline__ uint32_t lcg_skip(uint32_t s, uint64_t k) {
+  uint32_t a = kLcgA, c = kLcgC, A = 1u, C = 0u;  // x -> A x + C is k steps so far; x -> a x + c is 2^i steps
+  for (; k; k >>= 1) {
+    if (k & 1u) {
+      A = A * a;
+      C = C * a + c;
+    }
+    c = c * (a + 1u);
+    a = a * a;
+  }
+  return A * s + C;
+}
+__global__ void k_synth_lcg(uint8_t* __restrict__ frames, int w, int h, int first_frame, int nframes, uint32_t seed, int amp) {
+  const size_t ysz = (size_t)w * h, csz = ysz >> 2, fsz = ysz + 2 * csz, total = fsz * (size_t)nframes;
+  for (size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * kLcgRun; i0 < total; i0 += (size_t)gridDim.x * blockDim.x * kLcgRun) {
+    uint32_t s = lcg_skip(seed, (uint64_t)first_frame * fsz + i0);  // the state BEFORE this thread's first draw
+    for (size_t i = i0; i < i0 + kLcgRun && i < total; i++) {
+      s = s * kLcgA + kLcgC;
+      const size_t fr = i / fsz, o = i - fr * fsz;
+      const uint32_t n = (uint32_t)first_frame + (uint32_t)fr;
+      int a, basev;
+      if (o < ysz) {
+        const uint32_t x = (uint32_t)(o % (uint32_t)w), y = (uint32_t)(o / (uint32_t)w);
+        a = amp;
+        basev = 16 + (int)(((x + y + 7u * n) % (uint32_t)(w + h)) * 219u / (uint32_t)(w + h));
+      } else {
+        a = amp / 2;
+        basev = 128;
+      }
+      int v = basev + (int)((s >> 8) % (uint32_t)(2 * a + 1)) - a;
+      v = v < 0 ? 0 : (v > 255 ? 255 : v);
+      frames[i] = (uint8_t)v;
+    }
+  }
+}
+
 // ---- forward AAN butterfly (lib/RTjpeg.c:301-336 rows, :341-385 columns) ----
 __device__ __forceinline__ void fdct8(const int (&p)[8], int (&r)[8]) {
   const int a0 = p[0] + p[7], a7 = p[0] - p[7], a1 = p[1] + p[6], a6 = p[1] - p[6];
@@ -159,6 +203,118 @@ __global__ void k_encode_blocks(const uint8_t* __restrict__ frames, int w, int h
     }
   }
   lens[gb] = (uint8_t)n;
+}
+
+// The intra form, one WAVE per 64 horizontally adjacent blocks (the arrangement of k_decode: a macroblock group of 32
+// macroblocks has three parts — upper luma, lower luma, chroma — and a lane holds one block of its part), round 4:
+//   * a lane reads its block as eight 8-byte pieces of rows that the wave's lanes cover contiguously (k_encode_blocks
+//     reads byte by byte, one thread per block in stream order);
+//   * both transform passes and the quantiser in registers, every index a compile-time constant;
+//   * the run-length pack walks the zig-zag order fully unrolled (the coefficient of a slot is a REGISTER, not an
+//     indexed array in scratch memory) and appends bytes to the lane's 64-byte slot in LDS under lane predicates;
+//   * the slot leaves as four 16-byte stores.
+// Same arithmetic, same bytes (lib/RTjpeg.c:288-389 dctY, :245-252 quant, :109-155 b2s).  grid (3 * groups, frames).
+constexpr int kEncSlotStride = 80;  // LDS bytes per lane: a 64-byte slot + padding (16-byte reads without bank conflicts)
+__global__ __launch_bounds__(64) void k_encode_wave(const uint8_t* __restrict__ frames, int w, int h,
+                                                     const QTab* __restrict__ qt, uint8_t* __restrict__ slots,
+                                                     uint8_t* __restrict__ lens) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_slot[64 * kEncSlotStride];
+  const int lane = threadIdx.x;
+  const uint32_t mbw = (uint32_t)w / 16u, nmb = mbw * ((uint32_t)h / 16u);
+  const uint32_t grp = blockIdx.x / 3u, part = blockIdx.x - 3u * grp, fr = blockIdx.y;
+  const uint32_t dmb = part == 2u ? (uint32_t)(lane & 31) : (uint32_t)(lane >> 1);
+  const uint32_t k = part == 2u ? 4u + (uint32_t)(lane >> 5) : 2u * part + (uint32_t)(lane & 1);
+  const uint32_t mb = grp * (uint32_t)kMbPerGroup + dmb;
+  if (mb >= nmb) return;  // (no barrier below: a wave's lanes only touch their own slots)
+  const uint32_t my = mb / mbw, mx = mb - my * mbw;
+  const size_t ysz = (size_t)w * h;
+  const uint8_t* f = frames + (size_t)fr * (ysz + (ysz >> 1));
+  const uint8_t* src;
+  uint32_t stride;
+  if (k < 4u) {
+    stride = (uint32_t)w;
+    src = f + (size_t)(16u * my + 8u * (k >> 1)) * w + 16u * mx + 8u * (k & 1u);
+  } else {
+    stride = (uint32_t)w >> 1;
+    src = f + ysz + (k == 5u ? ysz >> 2 : 0) + (size_t)(8u * my) * stride + 8u * mx;
+  }
+  int ws[64];
+#pragma unroll
+  for (int row = 0; row < 8; row++) {
+    const uint2 d = *(const uint2*)(src + (size_t)row * stride);  // 8-byte aligned: widths are multiples of 16
+    int p[8] = {(int)(d.x & 255u), (int)((d.x >> 8) & 255u), (int)((d.x >> 16) & 255u), (int)(d.x >> 24),
+                (int)(d.y & 255u), (int)((d.y >> 8) & 255u), (int)((d.y >> 16) & 255u), (int)(d.y >> 24)};
+    int r[8];
+    fdct8(p, r);
+    r[0] <<= 8;
+    r[4] <<= 8;
+#pragma unroll
+    for (int c = 0; c < 8; c++) ws[8 * row + c] = r[c];
+  }
+  const int32_t* q = k < 4u ? qt->lqt : qt->cqt;
+  int blk[64];
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    int p[8], r[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++) p[kk] = ws[8 * kk + c];
+    fdct8(p, r);
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++) {
+      const int16_t d = (kk == 0 || kk == 4) ? (int16_t)((r[kk] + 128) >> 8) : (int16_t)((r[kk] + 32768) >> 16);
+      blk[8 * kk + c] = (int)(int16_t)(((int)d * q[8 * kk + c] + 32767) >> 16);  // RTjpeg_quant
+    }
+  }
+  // RTjpeg_b2s: DC clamped to 0..254, bt8 full-range bytes, then 7-bit values and zero runs (63 + run)
+  constexpr uint8_t zz[64] = MIRTJ_ZZ_INIT;
+  const int bt8 = k < 4u ? qt->lb8 : qt->cb8;  // the same for all lanes of a part
+  uint8_t* const out = s_slot + lane * kEncSlotStride;
+  int n = 0, run = 0;
+  {
+    const int v = blk[zz[0]];
+    out[n++] = (uint8_t)(v > 254 ? 254 : (v < 0 ? 0 : v));
+  }
+#pragma unroll
+  for (int z = 1; z < 64; z++) {
+    const int v = blk[zz[z]];
+    if (z <= kMaxRawBytes && z <= bt8) {  // (bt8 <= kMaxRawBytes: the host refuses other tables)
+      out[n++] = (uint8_t)(int8_t)(v > 127 ? 127 : (v < -128 ? -128 : v));
+    } else if (v != 0) {
+      if (run) {
+        out[n++] = (uint8_t)(63 + run);
+        run = 0;
+      }
+      out[n++] = (uint8_t)(int8_t)(v > 63 ? 63 : (v < -64 ? -64 : v));
+    } else {
+      run++;
+    }
+  }
+  if (run) out[n++] = (uint8_t)(63 + run);
+  const size_t gb = (size_t)fr * nmb * 6u + 6u * mb + k;
+  lens[gb] = (uint8_t)n;
+  const uint4* o4 = (const uint4*)out;
+  uint4* g4 = (uint4*)(slots + gb * 64);
+#pragma unroll
+  for (int i = 0; i < 4; i++) g4[i] = o4[i];
+}
+
+// Where the packets of a pass go: frame sizes (k_encode_scan) -> packet offsets in the output stream, each aligned to
+// `align`, continuing at the stream's cursor; both are kept on the device for all frames of the call, so that the host
+// has nothing to wait for between passes (round 3 synchronised twice per 32 frames).  One workgroup.
+__global__ __launch_bounds__(256) void k_encode_place(const uint32_t* __restrict__ frame_bytes, int m, uint32_t align,
+                                                       uint64_t* __restrict__ cursor, uint64_t* __restrict__ pkt_off,
+                                                       uint32_t* __restrict__ pkt_len, uint64_t* __restrict__ pass_off) {
+  if (threadIdx.x != 0) return;  // (a pass has at most a few hundred frames: a serial walk of them is microseconds)
+  uint64_t cur = *cursor;
+  for (int i = 0; i < m; i++) {
+    cur = (cur + align - 1u) / align * align;
+    const uint32_t len = frame_bytes[i] + 12u;
+    pkt_off[i] = cur;
+    pass_off[i] = cur;
+    pkt_len[i] = len;
+    cur += len;
+  }
+  *cursor = cur;
 }
 
 // One workgroup per frame: exclusive scan of the block lengths -> block offsets (relative to the

@@ -184,6 +184,12 @@ int mi_rtj_plan_read_index(mi_rtj_plan *plan, uint32_t *dst, size_t max_entries)
  * n frames numbered first_frame.., each 1.5*w*h bytes, back to back in d_frames. */
 int mi_rtj_synth_frames(mi_rtj_ctx *ctx, int w, int h, int first_frame, int n, uint32_t seed,
                         int amp, void *d_frames);
+/* The same pictures with the noise generator of SURVEY.md section 8d / BASELINE.md section 2: one linear congruential
+ * sequence s <- s * 1664525 + 1013904223 from `seed` (12345 there), one draw per sample in stream order (frame 0: Y row
+ * major, U, V; frame 1; ...), noise = ((s >> 8) mod (2a + 1)) - a.  first_frame continues the sequence where frame
+ * first_frame begins, so that ranks and passes make disjoint parts of ONE stream.  tests/rtjlib.py holds the numpy twin. */
+int mi_rtj_synth_frames_lcg(mi_rtj_ctx *ctx, int w, int h, int first_frame, int n, uint32_t seed,
+                            int amp, void *d_frames);
 /* Encode n frames (w x h, contiguous planes) at quality Q into d_stream, packets back to back
  * (each start aligned to `align` bytes, a power of two >= 1).  Host arrays pkt_offset/pkt_len
  * (n entries) receive the layout.  d_stream must hold mi_rtj_encode_bound(w,h,n,align) bytes. */

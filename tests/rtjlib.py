@@ -273,6 +273,40 @@ def synth_frame(w, h, n, seed=12345, amp=8):
     return np.concatenate([y, u, v])
 
 
+def synth_frame_lcg(w, h, n, seed=12345, amp=8):
+    """SURVEY.md 8d / BASELINE.md section 2's generator: the gradient of synth_frame with the noise of ONE linear
+    congruential sequence s <- s * 1664525 + 1013904223 over all frames (frame n starts at draw n * 1.5 w h)."""
+    fsz = w * h * 3 // 2
+    A, Cc, M = 1664525, 1013904223, 1 << 32
+    # skip ahead to the state before frame n's first draw
+    k, a, c, sa, sc = n * fsz, A, Cc, 1, 0
+    while k:
+        if k & 1:
+            sa, sc = (sa * a) % M, (sc * a + c) % M
+        c = (c * (a + 1)) % M
+        a = (a * a) % M
+        k >>= 1
+    s = (sa * seed + sc) % M
+    # the fsz states that follow, vectorised: s_j = A^j s + C (A^j - 1)/(A - 1), by doubling blocks
+    st = np.empty(fsz, np.uint64)
+    cur_a, cur_c, filled = np.uint64(A), np.uint64(Cc), 1
+    st[0] = (np.uint64(s) * np.uint64(A) + np.uint64(Cc)) & np.uint64(M - 1)
+    while filled < fsz:
+        m = min(filled, fsz - filled)
+        st[filled:filled + m] = (st[:m] * cur_a + cur_c) & np.uint64(M - 1)
+        cur_c = (cur_c * (cur_a + np.uint64(1))) & np.uint64(M - 1)
+        cur_a = (cur_a * cur_a) & np.uint64(M - 1)
+        filled += m
+    draw = (st >> np.uint64(8)).astype(np.int64)
+    xs = np.arange(w, dtype=np.int64)[None, :]
+    ys = np.arange(h, dtype=np.int64)[:, None]
+    base = (16 + ((xs + ys + 7 * n) % (w + h)) * 219 // (w + h)).reshape(-1)
+    y = np.clip(base + draw[:w * h] % (2 * amp + 1) - amp, 0, 255).astype(np.uint8)
+    ca = amp // 2
+    c2 = np.clip(128 + draw[w * h:] % (2 * ca + 1) - ca, 0, 255).astype(np.uint8)
+    return np.concatenate([y, c2])
+
+
 def digest(a):
     """Plane digest used by the golden fixtures (first 128 bits of SHA-256)."""
     import hashlib
