@@ -11,7 +11,8 @@ silent one-rank run.
 Workloads (`config.workload` in the output names the one that ran):
   frames1080  (default; BASELINE configs[1]) a "step" is one pass of the whole hot path (block-offset index +
               dequant/IDCT/plane scatter) over `--frames` distinct synthetic RTjpeg frames per GPU that are already
-              resident in HBM (coded 1920x1088 = display 1080p, YUV420, Q=255, intra only; SURVEY.md §8d cfg 2).
+              resident in HBM (coded 1920x1088 = display 1080p, YUV420, Q=255, intra only; SURVEY.md §8d cfg 2; content:
+              that section's generator, `--content lcg`, the default since round 4).
               Frames, streams and outputs never leave the device inside the timed region.  Weak scaling.
   streams4k   (configs[3]) one 3840x2160 stream WITH unchanged (0xFF) blocks per GPU, decoded in order through a
               pipelined session (mi_rtj_pipe_*, what the frame-owning plugin instance uses): host packets in, host
@@ -76,9 +77,9 @@ def parse():
     ap.add_argument("--quality", type=int, default=255)
     ap.add_argument("--amp", type=int, default=8, help="noise amplitude of the synthetic content")
     ap.add_argument("--seed", type=int, default=12345)
-    ap.add_argument("--content", choices=["hash", "lcg"], default="hash",
-                    help="noise of the synthetic pictures: hash = k_synth's counter-based hash (the default since round 1), "
-                         "lcg = SURVEY 8d / BASELINE.md section 2's linear congruential sequence (k_synth_lcg)")
+    ap.add_argument("--content", choices=["hash", "lcg"], default="lcg",
+                    help="noise of the synthetic pictures: lcg (default since round 4) = SURVEY 8d / BASELINE.md section 2's "
+                         "linear congruential sequence (k_synth_lcg), hash = k_synth's counter-based hash (rounds 1-3)")
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="budget of each CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU legs (and with them the parity check)")
     ap.add_argument("--no-stress", action="store_true", help="skip the short second measurement on noisy content")
@@ -252,9 +253,10 @@ def run_frames(a, dev, rank, n, amp, steps, warmup, barrier, sync_all, timed_unp
     w, h, Q = a.width, a.height, a.quality
     fsz = w * h * 3 // 2
     d_fr = (dev.synth_lcg if a.content == "lcg" else dev.synth)(w, h, rank * n, n, seed=a.seed, amp=amp)
+    d_st0 = dev.alloc(dev.encode_bound(w, h, n))  # (the stream's worst-case buffer, 51 GB at the default size: not the encoder's time)
     dev.sync()
     t_enc = time.perf_counter()
-    d_st, po, pl = dev.encode(w, h, Q, n, d_fr)  # the GPU encoder: synchronous, frames and stream resident in HBM
+    d_st, po, pl = dev.encode(w, h, Q, n, d_fr, d_stream=d_st0)  # the GPU encoder: synchronous, frames and stream resident in HBM
     dev.sync()
     t_enc = time.perf_counter() - t_enc
     dev.free(d_fr)
@@ -441,7 +443,11 @@ def main():
                          "traffic_source": (f"profiles/traffic.json ({prof.get('note', '')})" if traffic is not None else
                                             "none: the committed PMC profile was not taken from these kernel sources"),
                          "alg_bytes_per_launch": kernels[dom]["alg_bytes"], "ms_per_launch": kernels[dom]["ms"],
-                         "note": "vector-issue bound, not HBM bound: roofline_valu and DESIGN.md section 5"},
+                         "path_frac": round(alg_bytes * a.steps / dt / 1e9 / HBM_PEAK_GBS, 5),
+                         "note": "vector-issue bound, not HBM bound: roofline_valu and DESIGN.md section 5.  frac is the dominant "
+                                 "kernel's (k_decode = the transform step of a launch: k_decode_split or the classic form, and "
+                                 "k_decode_list, one pair of HIP events around them); path_frac is the whole step's — index and "
+                                 "transform — on the same algorithmic bytes"},
             "roofline_decode": {"bound": "hbm", "kernel": "k_decode", "achieved": dec["gbs"], "peak": HBM_PEAK_GBS,
                                 "unit": "GB/s", "frac": round((dec["gbs"] or 0.0) / HBM_PEAK_GBS, 5),
                                 "ms_per_launch": dec["ms"], "alg_bytes_per_launch": alg_bytes},

@@ -386,10 +386,15 @@ class MiRtj:
         self._chk(self.L.mi_rtj_synth_frames_lcg(self.h, w, h, first, n, seed, amp, d))
         return d
 
-    def encode(self, w, h, Q, n, d_frames, align=64, key_rate=0, lmask=0, cmask=0):
-        """Intra batch (key_rate 0) or one in-order stream with skip blocks (key_rate > 0)."""
+    def encode_bound(self, w, h, n, align=64):
+        return self.L.mi_rtj_encode_bound(w, h, n, align)
+
+    def encode(self, w, h, Q, n, d_frames, align=64, key_rate=0, lmask=0, cmask=0, d_stream=None):
+        """Intra batch (key_rate 0) or one in-order stream with skip blocks (key_rate > 0).  d_stream: a buffer of
+        encode_bound() bytes the caller allocated (else one is allocated here)."""
         bound = self.L.mi_rtj_encode_bound(w, h, n, align)
-        d_stream = self.alloc(bound)
+        if d_stream is None:
+            d_stream = self.alloc(bound)
         po = np.zeros(n, np.uint64)
         pl = np.zeros(n, np.uint32)
         if key_rate > 0:

@@ -52,9 +52,7 @@ def build(force=False, verbose=False, out=None):
             raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
         asm = os.path.join(tmp, "mi_rtjpeg-hip-amdgcn-amd-amdhsa-gfx950.s")
         chk = os.path.join(HERE, "..", "tools", "check_async_loads.py")
-        # (MI_RTJ_SKIP_ASYNC_CHECK=1: timing experiments only — the checker reads the text in layout order and takes a
-        # block the compiler merely PLACED behind the load block for one that runs behind it)
-        if os.path.exists(chk) and not os.environ.get("MI_RTJ_SKIP_ASYNC_CHECK"):
+        if os.path.exists(chk):  # (no way around it: round 3's MI_RTJ_SKIP_ASYNC_CHECK is gone)
             c = subprocess.run([sys.executable, chk, asm], capture_output=True, text=True)
             if c.returncode != 0:
                 raise RuntimeError("k_decode's hand-issued loads are not safe in this build:\n" + c.stdout + c.stderr)

@@ -39,7 +39,7 @@ __device__ __forceinline__ void dv_idct4(int x0, int x1, int x2, int x3, int (&a
 __device__ __forceinline__ uint32_t dv_peek(const uint32_t* buf, uint32_t bp) {
   const uint32_t i = bp >> 5, sh = bp & 31u;
   const uint32_t d0 = buf[i], d1 = buf[i + 1];
-  return sh ? (d0 << sh) | (d1 >> (32u - sh)) : d0;
+  return sh ? __builtin_amdgcn_alignbit(d0, d1, 32u - sh) : d0;
 }
 // OR `n` bits (the top n of v, n <= 32, the rest of v zero) into an LDS bit buffer at bit position bp
 __device__ __forceinline__ void dv_or_bits(uint32_t* buf, uint32_t bp, uint32_t v) {
@@ -93,11 +93,11 @@ __global__ __launch_bounds__(64) void k_dv_decode(const uint8_t* __restrict__ fr
   const int dc = (int)W0 >> 23;
   const uint32_t mode = (W0 >> 22) & 1u, cls = (W0 >> 20) & 3u;
   // consume n bits (1 <= n <= 31)
-  auto shift = [&](uint32_t n) {
+  auto shift = [&](uint32_t n) {  // one funnel shift per register: ({hi, lo} >> (32 - n)) is (hi << n) | (lo >> (32 - n))
     const uint32_t r = 32u - n;
-    W0 = (W0 << n) | (W1 >> r);
-    W1 = (W1 << n) | (W2 >> r);
-    W2 = (W2 << n) | (W3 >> r);
+    W0 = __builtin_amdgcn_alignbit(W0, W1, r);
+    W1 = __builtin_amdgcn_alignbit(W1, W2, r);
+    W2 = __builtin_amdgcn_alignbit(W2, W3, r);
     W3 <<= n;
   };
   shift(12u);

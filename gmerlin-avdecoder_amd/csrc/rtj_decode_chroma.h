@@ -32,11 +32,6 @@ namespace mirtj {
 constexpr int kPoolGroups = 3;  // groups per pooled round (17 busy blocks per group on the bench content: 51 of 64 lanes)
 constexpr int kPoolItersMax = 11;  // pooled rounds per wave at most (33 groups)
 
-// waves per frame that pool chroma: enough that a wave has at most kPoolItersMax rounds, odd like decode_slots()
-__host__ __device__ constexpr uint32_t chroma_pool_slots(uint32_t groups) {
-  const uint32_t sg = (groups + (uint32_t)kPoolGroups - 1u) / (uint32_t)kPoolGroups;
-  return ((sg + (uint32_t)kPoolItersMax - 1u) / (uint32_t)kPoolItersMax) | 1u;
-}
 
 #ifdef MIRTJ_EXPERIMENTS  // timing builds: shader-clock ticks per section of a pooling wave, summed over all waves
 __device__ unsigned long long g_pool_stamps[16];
@@ -425,26 +420,43 @@ __device__ __forceinline__ void chroma_pool_wave(uint32_t* __restrict__ s_lds, c
 }
 
 // ---------------------------------------------------------------------------------------
-// k_decode_split: the batch form of k_decode since round 4.  grid (luma slots + chroma slots, frames): workgroups
-// below `slots_y` are decode_wave waves that take the two luma parts of their groups in turn and leave blocks outside
-// the packed passes' budget to the list; the others pool chroma (above).  Without the one-value-per-register passes
-// the kernel needs far fewer vector registers than k_decode<true, false> did (108).
+// k_decode_split: the batch form of k_decode since round 4.  grid (8 * (L + C), frames): workgroup w of a frame is wave
+// r = w / 8 of XCD x = w % 8 (workgroups are dealt to the eight XCDs round-robin by their linear number, and 8 * (L + C)
+// per frame keeps that number's remainder the same for every frame).  An XCD owns the SUPER GROUPS (three consecutive
+// macroblock groups: what a pooling chroma wave takes per round) x, x + 8, x + 16, ...: its L luma waves take them in
+// turn (decode_wave, the two luma parts of each group; blocks outside the packed passes' budget go to the list), its C
+// chroma waves pool their chroma (above).  So the lines of a stretch of the packet and of its block offsets, which luma
+// and chroma waves both read, are fetched into ONE L2 — round 4's first version dealt the waves without regard to the
+// XCDs and fetched them twice (26.9 GB per launch instead of 13.8: profiles/r04/).  The affinity is for speed only:
+// nothing depends on which XCD a workgroup lands on.
 // ---------------------------------------------------------------------------------------
+constexpr uint32_t kXcds = 8;
+// luma / chroma waves per XCD and frame: a luma wave takes up to four super groups (12 groups, round 3's waves took 11),
+// a chroma wave up to kPoolItersMax
+__host__ __device__ constexpr uint32_t split_luma_waves(uint32_t groups) {
+  const uint32_t sg = (groups + (uint32_t)kPoolGroups - 1u) / (uint32_t)kPoolGroups, per_xcd = (sg + kXcds - 1u) / kXcds;
+  return per_xcd ? (per_xcd + 3u) / 4u : 1u;
+}
+__host__ __device__ constexpr uint32_t split_chroma_waves(uint32_t groups) {
+  const uint32_t sg = (groups + (uint32_t)kPoolGroups - 1u) / (uint32_t)kPoolGroups, per_xcd = (sg + kXcds - 1u) / kXcds;
+  return per_xcd ? (per_xcd + (uint32_t)kPoolItersMax - 1u) / (uint32_t)kPoolItersMax : 1u;
+}
 __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode_split(const FrameDev* __restrict__ frames,
                                                                const uint8_t* __restrict__ stream,
                                                                const QTab* __restrict__ lut,
                                                                const uint32_t* __restrict__ blkoff,
-                                                               uint8_t* __restrict__ outbuf, const uint32_t slots_y,
-                                                               const DecList list,
+                                                               uint8_t* __restrict__ outbuf, const uint32_t luma_waves,
+                                                               const uint32_t chroma_waves, const DecList list,
                                                                const uint32_t* __restrict__ only_in_mode) {
   if (only_in_mode && *only_in_mode != kDecModeSplit) return;  // the plan's policy has the classic form run (DecPolicy)
   __shared__ __attribute__((aligned(16))) uint32_t s_lds[kDecLdsWords];
-  if (blockIdx.x < slots_y)
-    decode_wave<true, false, 2, true>(s_lds, frames, blockIdx.y, blockIdx.x, slots_y, 0u, stream, lut, blkoff, outbuf,
-                                      nullptr, list);
-  else
-    chroma_pool_wave(s_lds, frames, blockIdx.y, blockIdx.x - slots_y, gridDim.x - slots_y, stream, lut, blkoff, outbuf,
-                     list);
+  const uint32_t x = blockIdx.x % kXcds, r = blockIdx.x / kXcds;
+  if (r < luma_waves)
+    decode_wave<true, false, 2, true, true>(s_lds, frames, blockIdx.y, x + kXcds * r, kXcds * luma_waves, 0u, stream, lut,
+                                            blkoff, outbuf, nullptr, list);
+  else if (chroma_waves)
+    chroma_pool_wave(s_lds, frames, blockIdx.y, x + kXcds * (r - luma_waves), kXcds * chroma_waves, stream, lut, blkoff,
+                     outbuf, list);
 }
 
 // k_decode_list: the parts k_decode_split left over, one wave per entry at a time, decode_wave's general path

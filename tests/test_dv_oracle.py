@@ -146,6 +146,33 @@ def test_the_library_exports_what_the_header_declares():
             dv.MiDv(0)
 
 
+def test_block_known_answers():
+    """(dc, mode, class, qno, levels) -> pixels: a block with nothing but DC is flat at 128 + dc / 2 in both modes; one
+    coefficient at (0, 1) is a horizontal half cosine whose amplitude doubles with every quantiser shift; in 2-4-8 mode
+    the coefficient at scan position 1 (the difference field's DC) alternates the lines"""
+    import ctypes as C
+    L = D.lib()
+    px = np.zeros(64, np.uint8)
+    lv = (C.c_int16 * 64)()
+    for mode in (0, 1):
+        for dc in (-256, -100, 0, 37, 255):
+            L.dvo_block_pixels(dc, mode, 0, 15, lv, D.p8(px))
+            want = min(255, max(0, (4 * dc + 1024 + 4) >> 3))
+            assert (px == want).all(), (mode, dc)
+    lv[1] = 12
+    L.dvo_block_pixels(0, 0, 0, 15, lv, D.p8(px))
+    a = px.reshape(8, 8).astype(int)
+    assert (a == a[0]).all() and (np.diff(a[0]) <= 0).all() and a[0, 0] > 128 > a[0, 7]  # (0,1): falls from left to right
+    amp0 = a[0, 0] - 128
+    L.dvo_block_pixels(0, 0, 3, 15, lv, D.p8(px))  # class 3 doubles the step
+    assert abs((int(px[0]) - 128) - 2 * amp0) <= 2
+    L.dvo_block_pixels(0, 0, 2, 0, lv, D.p8(px))   # class 2, quantisation number 0: area 0 is shifted by 3
+    assert abs((int(px[0]) - 128) - 8 * amp0) <= 6
+    L.dvo_block_pixels(0, 1, 0, 15, lv, D.p8(px))  # 2-4-8: scan position 1 is the difference field's DC
+    b = px.reshape(8, 8).astype(int)
+    assert (b[0::2] == b[0, 0]).all() and (b[1::2] == b[1, 0]).all() and b[0, 0] > 128 > b[1, 0]
+
+
 def test_golden_digests():
     """the statement does not drift: digests of an encoded frame and its picture (tests/golden/make_dv_golden.py)"""
     import json

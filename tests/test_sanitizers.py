@@ -24,14 +24,16 @@ def runtime(name):
 def test_host_c_suites_under_asan_and_ubsan():
     r = subprocess.run(["make", "-C", os.path.join(ROOT, "gmerlin-avdecoder_amd", "csrc"), "san"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    for f in ("libmi_qtrtj.so", "libmi_dvframe.so", "librtj_oracle.so", "plugin_harness.o", "video_rtjpeg_mi355x.o"):
+    for f in ("libmi_qtrtj.so", "libmi_dvframe.so", "librtj_oracle.so", "libdv_oracle.so", "plugin_harness.o", "video_rtjpeg_mi355x.o",
+              "video_dv_mi355x.o"):
         assert os.path.exists(os.path.join(SANDIR, f)), f
     env = dict(os.environ, MI_SAN_LIBDIR=SANDIR, LD_PRELOAD=runtime("libasan.so") + ":" + runtime("libubsan.so"),
                # python itself leaks by design; an error must kill the test process (abort), not just print
                ASAN_OPTIONS="detect_leaks=0:abort_on_error=1:allocator_may_return_null=1",
                UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    # (the DV statement decodes arbitrary bytes in its golden test: every bit reader and table of it under the sanitizers)
     suites = ["tests/test_qt_rtj0_host.py", "tests/test_dvframe_host.py", "tests/test_oracle_golden.py",
-              "tests/test_oracle_vs_reference.py"]
+              "tests/test_oracle_vs_reference.py", "tests/test_dv_oracle.py"]
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider"] + suites,
                        capture_output=True, text=True, env=env, cwd=ROOT, timeout=1500)
     tail = r.stdout[-3000:] + r.stderr[-3000:]
