@@ -615,18 +615,23 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out, int what = kL
       }
       uint32_t* const policy = p->split < 0 ? p->d_declist_cnt + 2 : nullptr;  // (forced split: no policy)
       const DecList list{p->d_declist_cnt + p->declist_flip, p->d_declist, (uint32_t)p->declist_cap};
-      const uint32_t lw = split_luma_waves(p->max_groups), cw = split_chroma_waves(p->max_groups);
+      uint32_t lw = split_luma_waves(p->max_groups);
+      uint32_t cw = split_chroma_waves(p->max_groups);
+      if (const char* e = exp_env("MI_RTJ_LUMA_WAVES")) lw = (uint32_t)atoi(e) ? (uint32_t)atoi(e) : lw;
+      if (const char* e = exp_env("MI_RTJ_CHROMA_WAVES")) cw = (uint32_t)atoi(e) ? (uint32_t)atoi(e) : cw;
       // (timing builds only, wrong pictures: MI_RTJ_SPLIT_ONLY = 1 the luma waves alone, 2 the chroma waves alone)
+      uint32_t xrot = kSplitXcdRot;
+      if (const char* e = exp_env("MI_RTJ_XCD_ROT")) xrot = (uint32_t)atoi(e);
       if (const char* only = exp_env("MI_RTJ_SPLIT_ONLY")) {
         if (atoi(only) == 1)
           hipLaunchKernelGGL(k_decode_split, dim3(kXcds * lw, drows), block, 0, ds, dfr, st, c->d_lut, blk, out8, lw, 0u, list,
-                             (const uint32_t*)nullptr);
+                             (const uint32_t*)nullptr, xrot);
         else
           hipLaunchKernelGGL(k_decode_split, dim3(kXcds * cw, drows), block, 0, ds, dfr, st, c->d_lut, blk, out8, 0u, cw, list,
-                             (const uint32_t*)nullptr);
+                             (const uint32_t*)nullptr, xrot);
       } else
       hipLaunchKernelGGL(k_decode_split, dim3(kXcds * (lw + cw), drows), block, 0, ds, dfr, st, c->d_lut, blk, out8, lw, cw,
-                         list, (const uint32_t*)policy);
+                         list, (const uint32_t*)policy, xrot);
       // the classic form: runs while the policy says so (returns at once otherwise: ~30 us of empty workgroups)
       if (policy)
         hipLaunchKernelGGL((k_decode<true, false>), grid, block, 0, ds, dfr, st, c->d_lut, blk, out8,

@@ -431,15 +431,21 @@ __device__ __forceinline__ void chroma_pool_wave(uint32_t* __restrict__ s_lds, c
 // nothing depends on which XCD a workgroup lands on.
 // ---------------------------------------------------------------------------------------
 constexpr uint32_t kXcds = 8;
-// luma / chroma waves per XCD and frame: a luma wave takes up to four super groups (12 groups, round 3's waves took 11),
-// a chroma wave up to kPoolItersMax
-__host__ __device__ constexpr uint32_t split_luma_waves(uint32_t groups) {
-  const uint32_t sg = (groups + (uint32_t)kPoolGroups - 1u) / (uint32_t)kPoolGroups, per_xcd = (sg + kXcds - 1u) / kXcds;
-  return per_xcd ? (per_xcd + 3u) / 4u : 1u;
-}
+constexpr uint32_t kSplitXcdRot = 1;  // stripes move on by one XCD per frame (k_decode_split)
+// luma / chroma waves per XCD and frame: a luma wave takes up to six super groups (18 groups; round 3's waves took 11), a
+// chroma wave up to kPoolItersMax.  How many there are of each decides more than how long they run: with L + C EVEN the
+// launch is 2 ... 25 % slower than with the odd counts next to it (1080p x 16,384, C = 1: L = 3 17.8 ms, 4 16.2, 5 16.6,
+// 7 19.8, 8 16.4, 9 17.0, 10 16.5, 11 21.0, 12 16.4, 13 17.4; two chroma waves of half the length 23 ... 24 ms:
+// profiles/r04/split_waves_per_xcd.txt) — an XCD deals its workgroups to its 32 CUs in turn, and an even period puts the
+// chroma waves, which run longest, on a fraction of them.  So L is made to leave L + C odd.
 __host__ __device__ constexpr uint32_t split_chroma_waves(uint32_t groups) {
   const uint32_t sg = (groups + (uint32_t)kPoolGroups - 1u) / (uint32_t)kPoolGroups, per_xcd = (sg + kXcds - 1u) / kXcds;
   return per_xcd ? (per_xcd + (uint32_t)kPoolItersMax - 1u) / (uint32_t)kPoolItersMax : 1u;
+}
+__host__ __device__ constexpr uint32_t split_luma_waves(uint32_t groups) {
+  const uint32_t sg = (groups + (uint32_t)kPoolGroups - 1u) / (uint32_t)kPoolGroups, per_xcd = (sg + kXcds - 1u) / kXcds;
+  const uint32_t lw = per_xcd ? (per_xcd + 5u) / 6u : 1u;
+  return ((lw + split_chroma_waves(groups)) & 1u) ? lw : lw + 1u;
 }
 __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode_split(const FrameDev* __restrict__ frames,
                                                                const uint8_t* __restrict__ stream,
@@ -447,10 +453,14 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode_split(c
                                                                const uint32_t* __restrict__ blkoff,
                                                                uint8_t* __restrict__ outbuf, const uint32_t luma_waves,
                                                                const uint32_t chroma_waves, const DecList list,
-                                                               const uint32_t* __restrict__ only_in_mode) {
+                                                               const uint32_t* __restrict__ only_in_mode,
+                                                               const uint32_t xcd_rot) {
   if (only_in_mode && *only_in_mode != kDecModeSplit) return;  // the plan's policy has the classic form run (DecPolicy)
   __shared__ __attribute__((aligned(16))) uint32_t s_lds[kDecLdsWords];
-  const uint32_t x = blockIdx.x % kXcds, r = blockIdx.x / kXcds;
+  // (the stripe of super groups an XCD owns moves on by xcd_rot from frame to frame: every XCD gets every stripe in turn)
+  const uint32_t x = (blockIdx.x + blockIdx.y * (xcd_rot & 7u)) % kXcds;
+  uint32_t r = blockIdx.x / kXcds;
+  if (xcd_rot & 256u) r = r < chroma_waves ? r + luma_waves : r - chroma_waves;  // (experiments: the chroma waves first)
   if (r < luma_waves)
     decode_wave<true, false, 2, true, true>(s_lds, frames, blockIdx.y, x + kXcds * r, kXcds * luma_waves, 0u, stream, lut,
                                             blkoff, outbuf, nullptr, list);

@@ -199,13 +199,107 @@ __device__ __forceinline__ uint32_t walk_record(const FrameDev& f, const uint8_t
   return k;
 }
 
+// walk_packet: walk_blocks for a whole packet, written for the issue rates of the scalar and the vector unit.  With
+// thousands of walkers resident the serial walk is bound by instruction issue (a SIMD issues one scalar and one vector
+// instruction per four cycles; walk_blocks' early-outs compile to ~46 scalar instructions per block, half of them
+// branches and flag shuffling).  Here:
+//   * a block is ONE straight path: the next position is selected between its two cases (unchanged block: 1 byte; else
+//     behind the byte whose weight sum reaches the target — tables whose blocks are all raw bytes are refused by the host,
+//     kMaxRawBytes) with scalar selects, and both windows are searched at once;
+//   * the macroblock's six blocks are unrolled, so the raw-byte count of a block is a loop constant;
+//   * of the window's bytes only "is 0xFF" is kept, as a lane mask in scalar registers (one compare per 64 bytes instead of
+//     a lane read per block), so nothing but the weight sums and the bytes in flight rotates when the window slides;
+//   * the stream is read through a buffer descriptor that returns 0 past the packet's end (no exec masking);
+//   * the offsets are gathered with v_writelane at a running lane and stored 64 at a time.
+__device__ __forceinline__ void walk_packet(const FrameDev& f, const uint8_t* __restrict__ stream,
+                                            const QTab* __restrict__ lut, uint32_t* __restrict__ out) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(stream + f.data_off), 0, (int)f.data_len, 0x00020000);
+  // a stream byte as int8 (the range check of a raw buffer covers the vector offset only: the position goes there)
+  auto fetch = [&](uint32_t pos) -> int {
+    return (int)(int8_t)__builtin_amdgcn_raw_buffer_load_b8(rs, (int)(pos + lane), 0, 0);
+  };
+  // token_weight() of an int8: 64..127 is a zero run of b - 63, anything else (<= 63, negative) one coefficient
+  auto weight = [](int b) -> uint32_t {
+    const int x = b - 63;
+    return (uint32_t)(x < 1 ? 1 : x > 64 ? 64 : x);
+  };
+  const uint32_t lb8 = (uint32_t)lut[f.qidx].lb8, cb8 = (uint32_t)lut[f.qidx].cb8;
+  const uint32_t need_l = 63u - lb8, need_c = 63u - cb8;
+  uint32_t base = 0, Wc, Wn;
+  int pf1, pf2, pf3;
+  unsigned long long ffc, ffn;  // lanes of the two windows that hold 0xFF ("unchanged block" where a block starts)
+  {
+    const int cur = fetch(0u), nxt = fetch(64u);
+    pf1 = fetch(128u);
+    pf2 = fetch(192u);
+    pf3 = fetch(256u);
+    Wc = wave_incl_scan(weight(cur));
+    Wn = wave_incl_scan(weight(nxt)) + (uint32_t)__builtin_amdgcn_readlane((int)Wc, 63);
+    ffc = __ballot(cur == -1);
+    ffn = __ballot(nxt == -1);
+  }
+  uint32_t lp = 0;     // the current block's start, relative to base
+  uint32_t j = 0;      // offsets gathered in acc since the last store
+  uint32_t acc = 0;
+  uint32_t* o = out;   // where acc's lane 0 goes
+  auto flush = [&]() {
+    if (lane < j) o[lane] = acc;
+    o += j;
+    j = 0;
+  };
+  auto step = [&](const uint32_t bt8, const uint32_t need, const int c) {  // c: the block's number in its macroblock
+    while (lp >= 64u) {  // slide the two windows forward
+      base += 64u;
+      lp -= 64u;
+      const int b = pf1;
+      pf1 = pf2;
+      pf2 = pf3;
+      pf3 = fetch(base + 256u);
+      Wc = Wn;
+      ffc = ffn;
+      Wn = wave_incl_scan(weight(b)) + (uint32_t)__builtin_amdgcn_readlane((int)Wc, 63);
+      ffn = __ballot(b == -1);
+    }
+    asm("s_add_i32 m0, %2, %3\n\tv_writelane_b32 %0, %1, m0" : "+v"(acc) : "s"(base + lp), "s"(j), "n"(c) : "m0", "scc");
+    const uint32_t iq = lp + bt8;  // last non-token byte of the block, 0..78
+    const uint32_t wq_c = (uint32_t)__builtin_amdgcn_readlane((int)Wc, (int)(iq & 63u));
+    const uint32_t wq_n = (uint32_t)__builtin_amdgcn_readlane((int)Wn, (int)(iq & 63u));
+    const uint32_t target = (iq < 64u ? wq_c : wq_n) + need;
+    // first byte whose sum reaches the target: in the first window, else in the second (W grows by >= 1 per byte, so
+    // it is there); find-first-set of nothing is 0xFFFFFFFF
+    const unsigned long long mc = __ballot(Wc >= target), mn = __ballot(Wn >= target);
+    uint32_t ec, en;
+    asm("s_ff1_i32_b64 %0, %1" : "=s"(ec) : "s"(mc));
+    asm("s_ff1_i32_b64 %0, %1" : "=s"(en) : "s"(mn));
+    en |= 64u;
+    const uint32_t e = ec < en ? ec : en;
+    asm("s_bitcmp1_b64 %1, %2\n\ts_cselect_b32 %0, %3, %4" : "=s"(lp) : "s"(ffc), "s"(lp), "s"(lp + 1u), "s"(e + 1u) : "scc");
+  };
+  for (uint32_t mb = 0; mb < f.nmb; ++mb) {
+    if (j > 58u) flush();
+    step(lb8, need_l, 0);
+    step(lb8, need_l, 1);
+    step(lb8, need_l, 2);
+    step(lb8, need_l, 3);
+    step(cb8, need_c, 4);
+    step(cb8, need_c, 5);
+    j += 6u;
+  }
+  if (j > 63u) flush();
+  asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(acc) : "s"(base + lp), "s"(j) : "m0");  // the end
+  j += 1u;
+  flush();
+}
+
 // Whole packet by one wave: the simple (serial) index, kept as the A/B baseline of the parallel one.
 __global__ __launch_bounds__(64) void k_index_walk(const FrameDev* __restrict__ frames,
                                                     const uint8_t* __restrict__ stream,
                                                     const QTab* __restrict__ lut,
                                                     uint32_t* __restrict__ blkoff) {
   const FrameDev f = frames[blockIdx.x];
-  walk_blocks(f, stream, lut, 0u, 0u, f.nmb * 6u, true, blkoff + f.blk_base);
+  walk_packet(f, stream, lut, blkoff + f.blk_base);
 }
 
 // The packets of a to-do list, a wave each (grid-stride): what k_spec_policy hands the serial walker when the list is long.
@@ -217,7 +311,7 @@ __global__ __launch_bounds__(64) void k_index_walk_todo(const FrameDev* __restri
   const uint32_t n = *ntodo;
   for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
     const FrameDev f = frames[todo[i]];
-    walk_blocks(f, stream, lut, 0u, 0u, f.nmb * 6u, true, blkoff + f.blk_base);
+    walk_packet(f, stream, lut, blkoff + f.blk_base);
   }
 }
 

@@ -107,3 +107,68 @@ def test_long_to_do_lists_go_to_the_serial_walker(monkeypatch):
         dev.free(d_stream)
         dev.free(d_out)
         dev.close()
+
+
+def test_the_serial_walker_on_built_and_arbitrary_streams(monkeypatch):
+    """walk_packet (the serial walker's loop: k_index_walk_todo, and k_index_walk under MI_RTJ_INDEX=serial) on streams that
+    are not an encoder's: maximal blocks, 1-byte (0xFF) blocks, unit runs and mixtures at two qualities (different raw-byte
+    counts for luma and chroma), macroblock counts around the walker's store rounds of 58-64 offsets, arbitrary bytes,
+    payloads shorter and longer than the picture needs, an empty payload — index and pictures as the oracle's."""
+    monkeypatch.setenv("MI_RTJ_INDEX", "serial")
+    rng = np.random.default_rng(99)
+    pkts, sizes = [], []
+    for (w, h) in [(16, 16), (160, 16), (176, 16), (336, 16), (352, 32), (1024, 64)]:
+        nblk = (w // 16) * (h // 16) * 6
+        for Q, mode in [(255, "long"), (255, "skip"), (255, "mix"), (100, "mix"), (20, "mix"), (200, "bytes"), (255, "short"), (90, "empty")]:
+            _, _, lb8, cb8, _, _ = R.oracle_tables(Q)
+            body = bytearray()
+            if mode == "bytes":
+                body = bytearray(rng.integers(0, 256, int(rng.integers(0, nblk * 70)), dtype=np.uint8).tobytes())
+            elif mode != "empty":
+                for b in range(nblk if mode != "short" else nblk // 2):
+                    bt8 = lb8 if (b % 6) < 4 else cb8
+                    kind = mode if mode not in ("mix", "short") else ["long", "skip", "one", "runs"][int(rng.integers(0, 4))]
+                    if kind == "skip":
+                        body.append(255)
+                        continue
+                    blk = [int(rng.integers(0, 255))] + [int(x) for x in rng.integers(0, 256, bt8)]
+                    left = 63 - bt8
+                    if kind == "long":
+                        blk += [int(x) & 0xFF for x in rng.integers(-64, 64, left)]
+                    elif kind == "one":
+                        blk.append(63 + left)
+                    else:
+                        while left > 0:
+                            r = int(rng.integers(1, min(left, 3) + 1))
+                            blk.append(63 + r)
+                            left -= r
+                    body += bytes(blk)
+            total = 12 + len(body)
+            hdr = bytes([total & 255, (total >> 8) & 255, (total >> 16) & 255, (total >> 24) & 255, 12, 0,
+                         w & 255, w >> 8, h & 255, h >> 8, Q, 0])
+            pkts.append(np.frombuffer(hdr + bytes(body), dtype=np.uint8).copy())
+            sizes.append((w, h))
+    dev = P.MiRtj()
+    d_stream, po, pl, hdrs = dev.upload_packets(pkts, align=1)
+    fs = [T.frame_bytes(w, h) for (w, h) in sizes]
+    offs = np.concatenate([[0], np.cumsum(fs)]).astype(np.uint64)
+    d_out = dev.alloc(int(offs[-1]))
+    dev.memset(d_out, 0x33, int(offs[-1]))
+    plan = dev.plan(hdrs, po, pl, offs[:-1])
+    plan.decode(d_stream, d_out)
+    dev.sync()
+    idx = plan.read_index()
+    dec = R.OracleDecoder()
+    at = 0
+    for i, p in enumerate(pkts):
+        w, h = sizes[i]
+        nblk = (w // 16) * (h // 16) * 6
+        want = np.full(fs[i], 0x33, np.uint8)
+        dec.decode(p, want)
+        assert np.array_equal(idx[at:at + nblk + 1], dec.block_offsets(p) - 12), i
+        at += nblk + 1
+        assert np.array_equal(dev.d2h(d_out, fs[i], offset=int(offs[i])), want), i
+    plan.close()
+    dev.free(d_stream)
+    dev.free(d_out)
+    dev.close()
