@@ -17,6 +17,9 @@ namespace midv {
 constexpr int kLaneStride = 144;  // bytes of LDS scratch per lane: 64 int16 coefficients + padding (16-byte reads without bank conflicts)
 constexpr int kMbufWords = 20;    // a macroblock's free space: at most 6 x 100 bits, + a dword to read past
 constexpr int kVbufWords = 86;    // a segment's: at most 2680 bits, + a dword to read past
+#ifndef MIDV_SKIP  // timing builds only (wrong pictures): 1 no pass 2 / 3, 2 no transforms and stores, 4 no pass 1
+#define MIDV_SKIP 0
+#endif
 
 __device__ __forceinline__ int dv_mul(int x, int c) { return (x * c + 128) >> 8; }
 // the scaled 8-point butterfly (lib/RTjpeg.c:2240-2283 as SURVEY.md appendix A.4 states it) and its even half
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(64) void k_dv_decode(const uint8_t* __restrict__ fr
   // (every loop of this kernel carries a bound no stream can reach — a code word is at least three bits long — so that a
   // wave always comes to its end whatever the tables or the bytes hold)
   bool act = live;
-  for (int guard = 0; guard < 48 && __any(act); guard++) {
+  for (int guard = 0; guard < ((MIDV_SKIP & 4) ? 0 : 48) && __any(act); guard++) {
     if (act) {
       const uint32_t e = lookup(W0), len = e & 31u;
       if (p + len > A) {
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(64) void k_dv_decode(const uint8_t* __restrict__ fr
   // lanes that want bits take turns, lowest lane of a group first, reading from the group's buffer until their block
   // is finished or the buffer is used up
   auto drain = [&](const unsigned long long gmask, const uint32_t* buf, uint32_t* gpos, const uint32_t glen) {
-    for (int turn = 0; turn < 64; turn++) {
+    for (int turn = 0; turn < ((MIDV_SKIP & 1) ? 0 : 64); turn++) {
       const bool want = live && !fin && *gpos < glen;
       const unsigned long long m = __ballot(want);
       if (m == 0ull) break;
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(64) void k_dv_decode(const uint8_t* __restrict__ fr
   }
 #endif
   // ---- inverse transform and placement ----
-  if (!live) return;
+  if (!live || (MIDV_SKIP & 2)) return;
   int c[64];
   {
     const uint4* q = (const uint4*)my;

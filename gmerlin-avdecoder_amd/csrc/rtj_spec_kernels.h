@@ -698,7 +698,14 @@ __global__ __launch_bounds__(256) void k_spec_policy(uint32_t n, uint32_t walker
     const bool lost = 2u * (uint64_t)todo_cnt[0] > n || 4u * (uint64_t)nf > walkers;
     const uint32_t level = state[kSpecStLong];  // 0 / 1 / 2: the lead of kSpecLead / kSpecLeadLong / kSpecLeadVery bytes
     if (level < 2u && (lost || 32u * (uint64_t)nf > walkers)) {
-      state[kSpecStLong] = level + 1u;  // many walkers lock late: the next longer lead
+      // many walkers lock late: the next longer lead — unless that is the longest and the launch is one the serial
+      // walker takes (serial_min): walkers with the longest lead parse four times their chunk, 37 ms per 16,384 packets of
+      // 1080p at +-32 where the serial walker takes 30 (profiles/r04/noisy_by_index.txt), so such a plan pauses instead
+      if (level == 1u && serial_min != 0u && n >= serial_min) {
+        state[kSpecStPause] = (uint32_t)kSpecPauseLaunches;
+      } else {
+        state[kSpecStLong] = level + 1u;
+      }
       state[kSpecStQuiet] = 0u;
       state[kSpecStLost] = 0u;
     } else if (level > 0u) {
