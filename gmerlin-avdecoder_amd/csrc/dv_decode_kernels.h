@@ -3,6 +3,8 @@
 //
 //   k_dv_decode    one wave per two video segments (2 x 5 compressed macroblocks = 60 blocks, one lane each):
 //                  the three passes of the variable-length decode, reconstruction, both inverse transforms, placement.
+//                  A workgroup is kDvWaves such waves that share the constant tables in LDS and nothing else: the only
+//                  workgroup barrier is the one behind the table load; everything after it is ordered inside a wave.
 //
 // A video segment is the unit nothing crosses: its 30 blocks share their unused bits (pass 2 inside a macroblock,
 // pass 3 across the segment), and its five macroblocks land in five different super blocks of the picture.  Integer
@@ -14,14 +16,35 @@
 
 namespace midv {
 
-constexpr int kLaneStride = 144;  // bytes of LDS scratch per lane: 64 int16 coefficients + padding (16-byte reads without bank conflicts)
+#ifndef MIDV_LANE_STRIDE
+#define MIDV_LANE_STRIDE 144
+#endif
+#ifndef MIDV_WAVES
+#define MIDV_WAVES 1
+#endif
+// bytes of LDS scratch per lane: 64 int16 coefficients + padding — 144: 16-byte reads without bank conflicts; 136: the
+// same for 8-byte reads (a lane's rows are then read as two halves)
+constexpr int kLaneStride = MIDV_LANE_STRIDE;
+static_assert(kLaneStride >= 128 && kLaneStride % 8 == 0, "a lane's scratch: 64 int16, rows 8-byte aligned");
+constexpr int kDvWaves = MIDV_WAVES;  // waves per workgroup (2.9 KB of tables per workgroup instead of per wave)
+constexpr int kDvLive = 60;       // lanes of a wave that hold a block
+constexpr int kDvPairs = kSegments / 2;                             // waves a frame needs
+constexpr int kDvGridX = (kDvPairs + kDvWaves - 1) / kDvWaves;      // workgroups per frame
 constexpr int kMbufWords = 20;    // a macroblock's free space: at most 6 x 100 bits, + a dword to read past
 constexpr int kVbufWords = 86;    // a segment's: at most 2680 bits, + a dword to read past
-#ifndef MIDV_SKIP  // timing builds only (wrong pictures): 1 no pass 2 / 3, 2 no transforms and stores, 4 no pass 1
+#ifndef MIDV_SKIP  // timing builds only (wrong pictures): 1 no pass 2 / 3, 2 no transforms and stores, 4 no pass 1, 8 transforms but no stores, 16 stores but no transforms
 #define MIDV_SKIP 0
 #endif
 
-__device__ __forceinline__ int dv_mul(int x, int c) { return (x * c + 128) >> 8; }
+// (x * c + 128) >> 8.  v_mad_i32_i24 is spelled out: every multiplicand of both passes stays below 2^23 in magnitude for
+// any block of int16 coefficients (the butterfly is the RTjpeg path's, whose bound tests/test_bounds.py derives; the
+// 2-4-8 column pass is its even half plus one addition), so the 24-bit multiplier is exact and wraps like the 32-bit
+// product — and the compiler, which cannot see the bound, would use the quarter-rate 32-bit multiplier for the row pass.
+__device__ __forceinline__ int dv_mul(int x, int c) {
+  int r;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(c), "v"(128));
+  return r >> 8;
+}
 // the scaled 8-point butterfly (lib/RTjpeg.c:2240-2283 as SURVEY.md appendix A.4 states it) and its even half
 __device__ __forceinline__ void dv_idct8(const int (&x)[8], int (&y)[8]) {
   const int t10 = x[0] + x[4], t11 = x[0] - x[4], t13 = x[2] + x[6], t12 = dv_mul(x[2] - x[6], 362) - t13;
@@ -51,31 +74,51 @@ __device__ __forceinline__ void dv_or_bits(uint32_t* buf, uint32_t bp, uint32_t 
   if (sh) atomicOr(&buf[i + 1], v << (32u - sh));
 }
 
-__global__ __launch_bounds__(64) void k_dv_decode(const uint8_t* __restrict__ frames, uint8_t* __restrict__ pics,
+// LDS traffic of one wave is ordered by the hardware (a wave's LDS instructions execute in order); what its lanes need
+// between a write and another lane's read is that the compiler keeps the order
+__device__ __forceinline__ void dv_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(64 * kDvWaves) void k_dv_decode(const uint8_t* __restrict__ frames, uint8_t* __restrict__ pics,
                                                    const Tables* __restrict__ T
 #ifdef MIDV_DEBUG
                                                    , int16_t* __restrict__ dbg  // [frame][workgroup][lane][64 coefficients + 8 state words]
 #endif
 ) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_coef[64 * kLaneStride];
+  __shared__ __attribute__((aligned(16))) uint8_t s_coef_all[kDvWaves][kDvLive * kLaneStride];
   __shared__ uint32_t s_lut9[512], s_lut2[64], s_tab[128], s_sh[24];
-  __shared__ uint32_t s_mbuf[10][kMbufWords], s_vbuf[2][kVbufWords];
-  __shared__ uint32_t s_mpos[10], s_mlen[10], s_vpos[2], s_vlen[2], s_excl[64];
+  __shared__ uint32_t s_mbuf_all[kDvWaves][10][kMbufWords], s_vbuf_all[kDvWaves][2][kVbufWords];
+  __shared__ uint32_t s_mpos_all[kDvWaves][10], s_mlen_all[kDvWaves][10], s_vpos_all[kDvWaves][2], s_vlen_all[kDvWaves][2],
+      s_excl_all[kDvWaves][64];
 
-  const int lane = threadIdx.x;
-  for (int i = lane; i < 512; i += 64) s_lut9[i] = T->lut9[i];
-  s_lut2[lane] = T->lut2[lane];
-  s_tab[lane] = T->tab[0][lane];
-  s_tab[64 + lane] = T->tab[1][lane];
-  if (lane < 24) s_sh[lane] = T->shift4[lane];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < 512; i += 64 * kDvWaves) s_lut9[i] = T->lut9[i];
+  if (tid < 64) s_lut2[tid] = T->lut2[tid];
+  if (tid < 128) s_tab[tid] = (&T->tab[0][0])[tid];
+  if (tid < 24) s_sh[tid] = T->shift4[tid];
+  uint8_t* const s_coef = s_coef_all[wv];
+  uint32_t(*const s_mbuf)[kMbufWords] = s_mbuf_all[wv];
+  uint32_t(*const s_vbuf)[kVbufWords] = s_vbuf_all[wv];
+  uint32_t* const s_mpos = s_mpos_all[wv];
+  uint32_t* const s_mlen = s_mlen_all[wv];
+  uint32_t* const s_vpos = s_vpos_all[wv];
+  uint32_t* const s_vlen = s_vlen_all[wv];
+  uint32_t* const s_excl = s_excl_all[wv];
   for (int i = lane; i < 10 * kMbufWords; i += 64) (&s_mbuf[0][0])[i] = 0u;
   for (int i = lane; i < 2 * kVbufWords; i += 64) (&s_vbuf[0][0])[i] = 0u;
+  __syncthreads();  // the tables are there (the workgroup's only barrier: every wave reaches it, before anything can end one)
+  const uint32_t pair = (uint32_t)blockIdx.x * (uint32_t)kDvWaves + wv;  // which two segments of the frame
+  if (pair >= (uint32_t)kDvPairs) return;
 
   // ---- which block this lane has ----
-  const bool live = lane < 60;
+  const bool live = lane < kDvLive;
   const uint32_t seg = (uint32_t)lane / 30u, b30 = (uint32_t)lane - 30u * seg, mbi = b30 / 6u, j = b30 - 6u * mbi;
   const uint32_t mb10 = (uint32_t)lane / 6u;  // macroblock of the wave, 0..9 (10: the idle lanes)
-  uint32_t S = 2u * blockIdx.x + seg;          // video segment of the frame
+  uint32_t S = 2u * pair + seg;                // video segment of the frame
   if (S >= (uint32_t)kSegments) S = kSegments - 1;  // (never: 270 is even)
   const uint32_t seq = S / 27u, slot = S - 27u * seq;
   const uint32_t v = 5u * slot + mbi;
@@ -105,14 +148,13 @@ __global__ __launch_bounds__(64) void k_dv_decode(const uint8_t* __restrict__ fr
   };
   shift(12u);
   uint32_t p = 12u;
-  uint8_t* const my = s_coef + lane * kLaneStride;
-  {
-    uint4* z = (uint4*)my;
+  uint8_t* const my = s_coef + (live ? lane : 0) * kLaneStride;  // (the idle lanes have no scratch and write none)
+  if (live) {
+    uint2* z = (uint2*)my;  // (pairs of these merge into 16-byte writes where the stride allows)
 #pragma unroll
-    for (int i = 0; i < 8; i++) z[i] = make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < 16; i++) z[i] = make_uint2(0, 0);
+    *(int16_t*)my = (int16_t)(dc * 4 + 1024 + 4);  // level shift and DESCALE's rounding term ride on the DC (both passes are linear in it)
   }
-  __syncthreads();
-  *(int16_t*)my = (int16_t)(dc * 4 + 1024 + 4);  // level shift and DESCALE's rounding term ride on the DC (both passes are linear in it)
   const uint32_t sh4 = s_sh[qno + (cls == 0u ? 6u : cls == 1u ? 3u : cls == 2u ? 0u : 1u)] + (cls == 3u ? 0x1111u : 0u);
   const uint32_t tab_m = 64u * mode;
 
@@ -171,7 +213,7 @@ __global__ __launch_bounds__(64) void k_dv_decode(const uint8_t* __restrict__ fr
       if (lane >= d) incl += o;
     }
     s_excl[lane] = incl - rem;
-    __syncthreads();
+    dv_wave_sync();
     const uint32_t base = s_excl[6u * mb10 < 64u ? 6u * mb10 : 63u];
     const uint32_t at = incl - rem - base;  // where this block's bits go in its macroblock's buffer
     if (live && j == 5u) {
@@ -190,7 +232,7 @@ __global__ __launch_bounds__(64) void k_dv_decode(const uint8_t* __restrict__ fr
       }
     }
   }
-  __syncthreads();
+  dv_wave_sync();
   // lanes that want bits take turns, lowest lane of a group first, reading from the group's buffer until their block
   // is finished or the buffer is used up
   auto drain = [&](const unsigned long long gmask, const uint32_t* buf, uint32_t* gpos, const uint32_t glen) {
@@ -224,7 +266,7 @@ __global__ __launch_bounds__(64) void k_dv_decode(const uint8_t* __restrict__ fr
         }
         *gpos = bp;
       }
-      __syncthreads();
+      dv_wave_sync();
     }
   };
   // ---- pass 2: inside the macroblock ----
@@ -236,7 +278,7 @@ __global__ __launch_bounds__(64) void k_dv_decode(const uint8_t* __restrict__ fr
     const bool allfin = (unf & (0x3Full << (6u * (mb10 < 10u ? mb10 : 0u)))) == 0ull;
     const uint32_t left = live && j == 0u && allfin ? s_mlen[mb10] - s_mpos[mb10] : 0u;
     s_excl[lane] = left;
-    __syncthreads();
+    dv_wave_sync();
     if (live && j == 0u) {
       uint32_t at = 0;
       for (uint32_t k = 0; k < mbi; k++) at += s_excl[30u * seg + 6u * k];
@@ -254,15 +296,15 @@ __global__ __launch_bounds__(64) void k_dv_decode(const uint8_t* __restrict__ fr
       }
     }
   }
-  __syncthreads();
+  dv_wave_sync();
   // ---- pass 3: across the segment ----
   drain(seg ? 0x3FFFFFFFull << 30 : 0x3FFFFFFFull, s_vbuf[seg < 2u ? seg : 1u], &s_vpos[seg < 2u ? seg : 1u],
         live ? s_vlen[seg] : 0u);
 
 #ifdef MIDV_DEBUG
   if (dbg) {
-    __syncthreads();
-    int16_t* o = dbg + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 + lane) * 72;
+    dv_wave_sync();
+    int16_t* o = dbg + (((size_t)blockIdx.y * kDvPairs + pair) * 64 + lane) * 72;
     for (int i = 0; i < 64; i++) o[i] = ((const int16_t*)my)[i];
     o[64] = (int16_t)pos; o[65] = (int16_t)p; o[66] = (int16_t)fin; o[67] = (int16_t)npart; o[68] = (int16_t)mode; o[69] = (int16_t)cls;
     o[70] = (int16_t)qno; o[71] = (int16_t)(live ? (mb10 < 10u ? s_mlen[mb10] : 0) : 0);
@@ -272,11 +314,11 @@ __global__ __launch_bounds__(64) void k_dv_decode(const uint8_t* __restrict__ fr
   if (!live || (MIDV_SKIP & 2)) return;
   int c[64];
   {
-    const uint4* q = (const uint4*)my;
+    const uint2* q = (const uint2*)my;
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-      const uint4 t = q[r];
-      const uint32_t d[4] = {t.x, t.y, t.z, t.w};
+      const uint2 t0 = q[2 * r], t1 = q[2 * r + 1];
+      const uint32_t d[4] = {t0.x, t0.y, t1.x, t1.y};
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         c[8 * r + 2 * k] = (int)(int16_t)(d[k] & 0xFFFFu);
@@ -285,7 +327,10 @@ __global__ __launch_bounds__(64) void k_dv_decode(const uint8_t* __restrict__ fr
     }
   }
   int ws[64];
-  if (mode == 0u) {
+  if (MIDV_SKIP & 16) {
+#pragma unroll
+    for (int i = 0; i < 64; i++) ws[i] = c[i];
+  } else if (mode == 0u) {
 #pragma unroll
     for (int h = 0; h < 8; h++) {
       int x[8], y[8];
@@ -335,7 +380,12 @@ __global__ __launch_bounds__(64) void k_dv_decode(const uint8_t* __restrict__ fr
   for (int r = 0; r < 8; r++) {
     int y[8];
     const int(&xr)[8] = *(const int(*)[8])(ws + 8 * r);
-    dv_idct8(xr, y);
+    if (MIDV_SKIP & 16) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) y[k] = xr[k];
+    } else {
+      dv_idct8(xr, y);
+    }
     uint32_t px[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -347,6 +397,7 @@ __global__ __launch_bounds__(64) void k_dv_decode(const uint8_t* __restrict__ fr
       px[k] = (uint32_t)s;
     }
     const uint32_t lo = px[0] | px[1] << 8 | px[2] << 16 | px[3] << 24, hi = px[4] | px[5] << 8 | px[6] << 16 | px[7] << 24;
+    if ((MIDV_SKIP & 8) && (lo != 0x12345678u || hi != 0x9ABCDEF0u)) continue;
     if (j >= 4u && edge) {  // the right-edge chroma block: left half here, right half eight lines below
       *(uint32_t*)(pic + org + (uint32_t)r * stride) = lo;
       *(uint32_t*)(pic + org + (uint32_t)(r + 8) * stride) = hi;

@@ -184,7 +184,7 @@ int mi_dv_decode_batch(mi_dv_ctx* c, const void* d_frames, int n, void* d_pics) 
     c->ev_used.erase(c->ev_used.begin());
   }
   DVCHK(c, hipEventRecord(ev.first, c->stream));
-  hipLaunchKernelGGL(k_dv_decode, dim3(kSegments / 2, (unsigned)n), dim3(64), 0, c->stream, (const uint8_t*)d_frames,
+  hipLaunchKernelGGL(k_dv_decode, dim3(kDvGridX, (unsigned)n), dim3(64 * kDvWaves), 0, c->stream, (const uint8_t*)d_frames,
                      (uint8_t*)d_pics, c->d_tab
 #ifdef MIDV_DEBUG
                      , (int16_t*)g_dbg

@@ -60,7 +60,7 @@ __device__ __forceinline__ void chroma_pool_wave(uint32_t* __restrict__ s_lds, c
   const uint32_t ngroups = (f.nmb + (uint32_t)kMbPerGroup - 1u) / (uint32_t)kMbPerGroup;
   const uint32_t nsg = (ngroups + (uint32_t)kPoolGroups - 1u) / (uint32_t)kPoolGroups;  // rounds of the frame
   if (slot >= nsg) return;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const QTab& qt = lut[f.qidx];
   if (qt.cb8 != 0) {  // tables with raw chroma bytes (none of RTjpeg_set_quality's): every group the general way
     if (lane == 0)
@@ -74,7 +74,7 @@ __device__ __forceinline__ void chroma_pool_wave(uint32_t* __restrict__ s_lds, c
     s_tab[kSlotTabN + lane] = ((uint32_t)qt.ciqt[nat] << 16) | (uint32_t)coef_byte(nat);
     if (lane < kSlotTabN - 64) s_tab[kSlotTabN + 64 + lane] = 128u;
   }
-  __syncthreads();  // one wave: orders the table write before the lanes' reads
+  wave_lds_sync();  // orders the table write before the lanes' reads (the table is the wave's own)
   const uint32_t lds0 = lds_address(s_lds);
   const uint32_t my_a = lds0 + (uint32_t)lane * (uint32_t)(kCoefStride * 2);
   const uint4* my = (const uint4*)((const uint8_t*)s_lds + (size_t)lane * (kCoefStride * 2));
@@ -347,7 +347,10 @@ __device__ __forceinline__ void chroma_pool_wave(uint32_t* __restrict__ s_lds, c
                 ov.x = *(const lds_u32_t*)(uintptr_t)ra;
                 ov.y = *(const lds_u32_t*)(uintptr_t)(ra + 4u);
               }
-              __builtin_nontemporal_store(ov, (mirtj_u32x2*)(plane + o));
+              // plain stores: as nontemporal ones these 8-byte-per-lane rows reached memory as 22.8 GB per launch for
+              // 17.1 GB of chroma planes (WRITE_SIZE; whatever the row alignment), plain ones as 17.2; the time is the
+              // same (profiles/r04/chroma_store_traffic.txt)
+              *(mirtj_u32x2*)(plane + o) = ov;
               plane += stride;
               ra += 8u;
             }

@@ -575,6 +575,14 @@ constexpr int kDecLdsWords = kCoefWords + 2 * kSlotTabN + MIRTJ_DEC_LDS_PAD;  //
 // parts, so whole row segments (partial-line writes are what made round 2's deferred blocks slow).  The capacity is
 // every part of every group of the launch: the list cannot overflow.
 // ---------------------------------------------------------------------------------------
+// LDS traffic of ONE wave is ordered by the hardware (a wave's LDS instructions execute in order); what the lanes of a
+// wave need between a write and another lane's read is that the compiler keeps the order: fences at wavefront scope.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 struct DecList {
   uint32_t* count;
   uint2* items;
@@ -590,7 +598,7 @@ constexpr uint32_t kDecClassicLaunches = 64u;
 __device__ __forceinline__ void declist_push(const DecList& L, uint32_t fidx, uint32_t grp, uint32_t part) {
   // called by the lanes of a (possibly divergent) branch with wave-uniform arguments: the first active lane appends
   const unsigned long long m = __ballot(1);
-  if ((uint32_t)threadIdx.x == (uint32_t)__builtin_ctzll(m)) {
+  if (((uint32_t)threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m)) {
     const uint32_t i = atomicAdd(L.count, 1u);
     if (i < L.cap) L.items[i] = make_uint2(fidx, grp | (part << 28));
   }
@@ -741,7 +749,7 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
     return 3u * (slot + q * slots) + (g - 3u * q);
   };
   if (group_of(0u) >= ngroups) return;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const uint32_t* off = uniform_ptr(blkoff + f.blk_base);
   const QTab& qt = lut[f.qidx];
   {
@@ -754,7 +762,7 @@ __device__ __forceinline__ void decode_wave(uint32_t* __restrict__ s_lds, const 
       s_tab[kSlotTabN + 64 + lane] = 128u;
     }
   }
-  __syncthreads();  // one wave: orders the table write before the lanes' reads
+  wave_lds_sync();  // orders the table write before the lanes' reads (the table is the wave's own)
   const uint32_t my_a = lds_address(s_lds) + (uint32_t)lane * (uint32_t)(kCoefStride * 2);
   const int k63 = 63;
   const uint4* my = (const uint4*)((const uint8_t*)s_lds + (size_t)lane * (kCoefStride * 2));

@@ -309,8 +309,19 @@ typedef struct {
 static void bb_put(bitbuf *b, const uint8_t *bytes, int from, int to) {
   for (int i = from; i < to; i++) b->bit[b->n++] = (bytes[i >> 3] >> (7 - (i & 7))) & 1;
 }
+/* statistics for the design notes (not thread safe): code words completed in pass 1 / 2 / 3, blocks entering pass 2 / 3 */
+static long stat_words[3], stat_blocks[3];
+static int stat_pass;
+void dvo_pass_stats(long words[3], long blocks[3], int reset) {
+  for (int i = 0; i < 3; i++) {
+    words[i] = stat_words[i];
+    blocks[i] = stat_blocks[i];
+    if (reset) stat_words[i] = stat_blocks[i] = 0;
+  }
+}
 /* the block reads code words from b until it is finished or b is used up (a cut-off word stays with the block) */
 static void decode_ac(blk_t *k, bitbuf *b) {
+  stat_blocks[stat_pass]++;
   while (k->pos < 64) {
     const int avail = k->npart + (b->n - b->rd);
     uint32_t w = k->part; /* k->npart bits */
@@ -326,6 +337,7 @@ static void decode_ac(blk_t *k, bitbuf *b) {
     b->rd += e->len - k->npart;
     k->part = 0;
     k->npart = 0;
+    stat_words[stat_pass]++;
     if (e->run == 255) {
       k->pos = 64;
       return;
@@ -360,11 +372,13 @@ static void decode_segment(const uint8_t *dif, int seq, int slot, uint8_t *pic, 
       bitbuf own;
       own.n = own.rd = 0;
       bb_put(&own, a, 12, area_bits(j));
+      stat_pass = 0;
       decode_ac(k, &own);
       if (k->pos == 64) bb_put(&mbuf[m], a, 12 + own.rd, area_bits(j)); /* what a finished block leaves is the macroblock's */
     }
     int all = 1;
     for (int j = 0; j < 6; j++) { /* pass 2: unfinished blocks, in order, from the macroblock's space */
+      stat_pass = 1;
       if (blk[m][j].pos < 64 && mbuf[m].rd < mbuf[m].n) decode_ac(&blk[m][j], &mbuf[m]);
       all = all && blk[m][j].pos == 64;
     }
@@ -373,7 +387,10 @@ static void decode_segment(const uint8_t *dif, int seq, int slot, uint8_t *pic, 
   }
   for (int m = 0; m < 5; m++) /* pass 3 */
     for (int j = 0; j < 6; j++)
-      if (blk[m][j].pos < 64 && vbuf.rd < vbuf.n) decode_ac(&blk[m][j], &vbuf);
+      if (blk[m][j].pos < 64 && vbuf.rd < vbuf.n) {
+        stat_pass = 2;
+        decode_ac(&blk[m][j], &vbuf);
+      }
   if (coefs) {
     for (int m = 0; m < 5; m++)
       for (int j = 0; j < 6; j++) memcpy(coefs[6 * m + j], blk[m][j].coef, sizeof blk[m][j].coef);

@@ -56,6 +56,10 @@ int dvo_vlc_lookup(uint32_t bits16, int *len, int *run, int *level);
 /* synthetic content: picture n of a seeded sequence (gradient, noise of amplitude amp, a combed band for the 2-4-8 mode) */
 void dvo_synth(uint8_t *pic, int n, uint32_t seed, int amp);
 
+/* design-note statistics (not thread safe): code words completed in pass 1 / 2 / 3 and blocks that read in each pass since
+ * the last reset */
+void dvo_pass_stats(long words[3], long blocks[3], int reset);
+
 #ifdef __cplusplus
 }
 #endif
