@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include "dv_common.h"
+#include "rtj_idct_pk.h"  // the packed passes of the RTjpeg path: the butterfly is the same
 
 namespace midv {
 
@@ -22,17 +23,16 @@ namespace midv {
 #ifndef MIDV_WAVES
 #define MIDV_WAVES 1
 #endif
-// bytes of LDS scratch per lane: 64 int16 coefficients + padding — 144: 16-byte reads without bank conflicts; 136: the
-// same for 8-byte reads (a lane's rows are then read as two halves)
+// bytes of LDS scratch per lane: 64 int16 coefficients + padding (144: 16-byte reads without bank conflicts)
 constexpr int kLaneStride = MIDV_LANE_STRIDE;
-static_assert(kLaneStride >= 128 && kLaneStride % 8 == 0, "a lane's scratch: 64 int16, rows 8-byte aligned");
+static_assert(kLaneStride >= 128 && kLaneStride % 16 == 0, "a lane's scratch: 64 int16, read 16 bytes at a time");
 constexpr int kDvWaves = MIDV_WAVES;  // waves per workgroup (2.9 KB of tables per workgroup instead of per wave)
 constexpr int kDvLive = 60;       // lanes of a wave that hold a block
 constexpr int kDvPairs = kSegments / 2;                             // waves a frame needs
 constexpr int kDvGridX = (kDvPairs + kDvWaves - 1) / kDvWaves;      // workgroups per frame
 constexpr int kMbufWords = 20;    // a macroblock's free space: at most 6 x 100 bits, + a dword to read past
 constexpr int kVbufWords = 86;    // a segment's: at most 2680 bits, + a dword to read past
-#ifndef MIDV_SKIP  // timing builds only (wrong pictures): 1 no pass 2 / 3, 2 no transforms and stores, 4 no pass 1, 8 transforms but no stores, 16 stores but no transforms
+#ifndef MIDV_SKIP  // timing builds only (wrong pictures): 1 no pass 2 / 3, 2 no transforms and stores, 4 no pass 1
 #define MIDV_SKIP 0
 #endif
 
@@ -74,6 +74,50 @@ __device__ __forceinline__ void dv_or_bits(uint32_t* buf, uint32_t bp, uint32_t 
   if (sh) atomicOr(&buf[i + 1], v << (32u - sh));
 }
 
+// ---- two int16 values to a register (rtj_idct_pk.h: exact while the range test there holds) ----
+__device__ __forceinline__ uint32_t dv_pk_add(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_add_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ uint32_t dv_pk_sub(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_sub_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// (x * 362 + 128) >> 8 in both halves, modulo 2^16
+__device__ __forceinline__ uint32_t dv_pk_mul362(uint32_t x, const mirtj::IdctPK& K) {
+  uint32_t pl, ph, r;
+  asm("v_mad_i32_i16 %0, %3, %4, %5\n\t"
+      "v_mad_i32_i16 %1, %3, %4, %5 op_sel:[1,0,0,0]\n\t"
+      "v_perm_b32 %2, %1, %0, %6"
+      : "=&v"(pl), "=&v"(ph), "=v"(r)
+      : "v"(x), "s"(K.k362), "v"(K.c128), "s"(K.sel_m));
+  return r;
+}
+// the 2-4-8 column pass on a column pair: x[r] = (row r of the even column | of the odd one << 16); rows 0, 2, 4, 6 are
+// the 4-point transform of the fields' sum, rows 1, 3, 5, 7 of their difference (dv_idct4 twice, then sum / difference).
+// Every linear form here is one of the 8-8 pass's even half or a sum of two of them over disjoint coefficients, so the
+// range test's weights (rtj_idct_pk.h) cover it.
+__device__ __forceinline__ void dv_col248_pk(uint32_t (&x)[8], const mirtj::IdctPK& K) {
+  uint32_t a[4], b[4];
+  auto idct4 = [&](uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, uint32_t(&o)[4]) {
+    const uint32_t t10 = dv_pk_add(p0, p2), t11 = dv_pk_sub(p0, p2), t13 = dv_pk_add(p1, p3);
+    const uint32_t t12 = dv_pk_sub(dv_pk_mul362(dv_pk_sub(p1, p3), K), t13);
+    o[0] = dv_pk_add(t10, t13);
+    o[3] = dv_pk_sub(t10, t13);
+    o[1] = dv_pk_add(t11, t12);
+    o[2] = dv_pk_sub(t11, t12);
+  };
+  idct4(x[0], x[2], x[4], x[6], a);
+  idct4(x[1], x[3], x[5], x[7], b);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    x[2 * i] = dv_pk_add(a[i], b[i]);
+    x[2 * i + 1] = dv_pk_sub(a[i], b[i]);
+  }
+}
+
 // LDS traffic of one wave is ordered by the hardware (a wave's LDS instructions execute in order); what its lanes need
 // between a write and another lane's read is that the compiler keeps the order
 __device__ __forceinline__ void dv_wave_sync() {
@@ -97,8 +141,8 @@ __global__ __launch_bounds__(64 * kDvWaves) void k_dv_decode(const uint8_t* __re
   const int tid = threadIdx.x, lane = tid & 63;
   const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
   for (int i = tid; i < 512; i += 64 * kDvWaves) s_lut9[i] = T->lut9[i];
-  if (tid < 64) s_lut2[tid] = T->lut2[tid];
-  if (tid < 128) s_tab[tid] = (&T->tab[0][0])[tid];
+  for (int i = tid; i < 64; i += 64 * kDvWaves) s_lut2[i] = T->lut2[i];
+  for (int i = tid; i < 128; i += 64 * kDvWaves) s_tab[i] = (&T->tab[0][0])[i];
   if (tid < 24) s_sh[tid] = T->shift4[tid];
   uint8_t* const s_coef = s_coef_all[wv];
   uint32_t(*const s_mbuf)[kMbufWords] = s_mbuf_all[wv];
@@ -305,54 +349,26 @@ __global__ __launch_bounds__(64 * kDvWaves) void k_dv_decode(const uint8_t* __re
   if (dbg) {
     dv_wave_sync();
     int16_t* o = dbg + (((size_t)blockIdx.y * kDvPairs + pair) * 64 + lane) * 72;
-    for (int i = 0; i < 64; i++) o[i] = ((const int16_t*)my)[i];
+    for (int i = 0; i < 64; i++)  // natural order out of the scratch's (column pair, row) layout
+      o[i] = ((const int16_t*)my)[2 * (8 * ((i & 7) >> 1) + (i >> 3)) + (i & 1)];
     o[64] = (int16_t)pos; o[65] = (int16_t)p; o[66] = (int16_t)fin; o[67] = (int16_t)npart; o[68] = (int16_t)mode; o[69] = (int16_t)cls;
     o[70] = (int16_t)qno; o[71] = (int16_t)(live ? (mb10 < 10u ? s_mlen[mb10] : 0) : 0);
   }
 #endif
   // ---- inverse transform and placement ----
-  if (!live || (MIDV_SKIP & 2)) return;
-  int c[64];
+  // The scratch holds the block as the RTjpeg path's does (dv_tables.cpp): dword (column pair j, row r) at 8 j + r.  A wave
+  // whose blocks all pass the 16-bit range test takes the packed passes (two values to a register: rtj_idct_pk.h, and
+  // dv_col248_pk for 2-4-8 blocks); any other wave the 32-bit ones below.  Both are the statement's arithmetic exactly.
+  mirtj::IdctPK K = mirtj::idct_pk_constants();
+  K.c235 = 0x00FF00FFu;  // pixels clamp to 0..255 here
+  uint4 q[8];
   {
-    const uint2* q = (const uint2*)my;
+    const uint4* qq = (const uint4*)my;
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-      const uint2 t0 = q[2 * r], t1 = q[2 * r + 1];
-      const uint32_t d[4] = {t0.x, t0.y, t1.x, t1.y};
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        c[8 * r + 2 * k] = (int)(int16_t)(d[k] & 0xFFFFu);
-        c[8 * r + 2 * k + 1] = (int)d[k] >> 16;
-      }
-    }
+    for (int i = 0; i < 8; i++) q[i] = qq[i];
   }
-  int ws[64];
-  if (MIDV_SKIP & 16) {
-#pragma unroll
-    for (int i = 0; i < 64; i++) ws[i] = c[i];
-  } else if (mode == 0u) {
-#pragma unroll
-    for (int h = 0; h < 8; h++) {
-      int x[8], y[8];
-#pragma unroll
-      for (int r = 0; r < 8; r++) x[r] = c[8 * r + h];
-      dv_idct8(x, y);
-#pragma unroll
-      for (int r = 0; r < 8; r++) ws[8 * r + h] = y[r];
-    }
-  } else {  // 2-4-8: rows 2v / 2v + 1 hold the sum / the difference of the two fields
-#pragma unroll
-    for (int h = 0; h < 8; h++) {
-      int a[4], b[4];
-      dv_idct4(c[h], c[16 + h], c[32 + h], c[48 + h], a);
-      dv_idct4(c[8 + h], c[24 + h], c[40 + h], c[56 + h], b);
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        ws[8 * (2 * i) + h] = a[i] + b[i];
-        ws[8 * (2 * i + 1) + h] = a[i] - b[i];
-      }
-    }
-  }
+  const bool pk = __all(!live || mirtj::pk_range_full(q, K));
+  if (!live || (MIDV_SKIP & 2)) return;
   // where the block goes (525/60 4:1:1 macroblock shuffling and placement)
   uint32_t x32, y8;
   {
@@ -376,16 +392,80 @@ __global__ __launch_bounds__(64 * kDvWaves) void k_dv_decode(const uint8_t* __re
     stride = kCW;
     org = kW * kH + (j == 4u ? kCW * kH : 0u) + 8u * y8 * kCW + 8u * x32;  // block 4 is Cr (third plane), block 5 Cb
   }
+  const bool halves = j >= 4u && edge;  // the right-edge chroma block: left half here, right half eight lines below
+  auto put = [&](int r, uint32_t lo, uint32_t hi) {
+    if (halves) {
+      *(uint32_t*)(pic + org + (uint32_t)r * stride) = lo;
+      *(uint32_t*)(pic + org + (uint32_t)(r + 8) * stride) = hi;
+    } else {
+      u32x2a o;
+      o.x = lo;
+      o.y = hi;
+      *(u32x2a*)(pic + org + (uint32_t)r * stride) = o;
+    }
+  };
+  if (pk) {
+    uint32_t y[4][8];
+#pragma unroll
+    for (int jj = 0; jj < 4; jj++) {
+      uint32_t x[8] = {q[2 * jj].x, q[2 * jj].y, q[2 * jj].z, q[2 * jj].w, q[2 * jj + 1].x, q[2 * jj + 1].y, q[2 * jj + 1].z, q[2 * jj + 1].w};
+      if (mode == 0u)
+        mirtj::idct8_pk_col<false>(x, K);
+      else
+        dv_col248_pk(x, K);
+#pragma unroll
+      for (int r = 0; r < 8; r++) y[jj][r] = x[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r += 2) {
+      uint32_t ya[4] = {y[0][r], y[1][r], y[2][r], y[3][r]}, yb[4] = {y[0][r + 1], y[1][r + 1], y[2][r + 1], y[3][r + 1]};
+      uint2 a, b;
+      mirtj::idct8_pk_row_px<0>(ya, yb, a, b, K);
+      put(r, a.x, a.y);
+      put(r + 1, b.x, b.y);
+    }
+    return;
+  }
+  int c[64];
+#pragma unroll
+  for (int jj = 0; jj < 4; jj++) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const uint4& t = q[2 * jj + (r >> 2)];
+      const uint32_t d = (r & 3) == 0 ? t.x : (r & 3) == 1 ? t.y : (r & 3) == 2 ? t.z : t.w;
+      c[8 * r + 2 * jj] = (int)(int16_t)(d & 0xFFFFu);
+      c[8 * r + 2 * jj + 1] = (int)d >> 16;
+    }
+  }
+  int ws[64];
+  if (mode == 0u) {
+#pragma unroll
+    for (int h = 0; h < 8; h++) {
+      int x[8], y[8];
+#pragma unroll
+      for (int r = 0; r < 8; r++) x[r] = c[8 * r + h];
+      dv_idct8(x, y);
+#pragma unroll
+      for (int r = 0; r < 8; r++) ws[8 * r + h] = y[r];
+    }
+  } else {  // 2-4-8: rows 2v / 2v + 1 hold the sum / the difference of the two fields
+#pragma unroll
+    for (int h = 0; h < 8; h++) {
+      int a[4], b[4];
+      dv_idct4(c[h], c[16 + h], c[32 + h], c[48 + h], a);
+      dv_idct4(c[8 + h], c[24 + h], c[40 + h], c[56 + h], b);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        ws[8 * (2 * i) + h] = a[i] + b[i];
+        ws[8 * (2 * i + 1) + h] = a[i] - b[i];
+      }
+    }
+  }
 #pragma unroll
   for (int r = 0; r < 8; r++) {
     int y[8];
     const int(&xr)[8] = *(const int(*)[8])(ws + 8 * r);
-    if (MIDV_SKIP & 16) {
-#pragma unroll
-      for (int k = 0; k < 8; k++) y[k] = xr[k];
-    } else {
-      dv_idct8(xr, y);
-    }
+    dv_idct8(xr, y);
     uint32_t px[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -396,17 +476,7 @@ __global__ __launch_bounds__(64 * kDvWaves) void k_dv_decode(const uint8_t* __re
       s = s < 0 ? 0 : s > 255 ? 255 : s;
       px[k] = (uint32_t)s;
     }
-    const uint32_t lo = px[0] | px[1] << 8 | px[2] << 16 | px[3] << 24, hi = px[4] | px[5] << 8 | px[6] << 16 | px[7] << 24;
-    if ((MIDV_SKIP & 8) && (lo != 0x12345678u || hi != 0x9ABCDEF0u)) continue;
-    if (j >= 4u && edge) {  // the right-edge chroma block: left half here, right half eight lines below
-      *(uint32_t*)(pic + org + (uint32_t)r * stride) = lo;
-      *(uint32_t*)(pic + org + (uint32_t)(r + 8) * stride) = hi;
-    } else {
-      u32x2a o;
-      o.x = lo;
-      o.y = hi;
-      *(u32x2a*)(pic + org + (uint32_t)r * stride) = o;
-    }
+    put(r, px[0] | px[1] << 8 | px[2] << 16 | px[3] << 24, px[4] | px[5] << 8 | px[6] << 16 | px[7] << 24);
   }
 }
 

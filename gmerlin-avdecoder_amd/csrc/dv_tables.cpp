@@ -82,7 +82,10 @@ bool build_tables(Tables* t) {
       const uint32_t q = (uint32_t)floor(16384.0 * aan[h] * aan[v] / (w[h] * w[v]) + 0.5);
       if (q >= 65536u) return false;
       const uint32_t area = k < 6 ? 0u : k < 21 ? 1u : k < 43 ? 2u : 3u;
-      t->tab[mode][k] = (q << 16) | (area << 8) | (uint32_t)(2 * nat);  // int16 coefficients in natural order
+      // where the coefficient goes in a lane's scratch: columns in pairs, dword (column pair j, row r) at 8 j + r — rows
+      // 0-3 / 4-7 of a pair are 16 bytes each, what the packed column pass reads (rtj_idct_pk.h)
+      const uint32_t where = 4u * (8u * (uint32_t)(h >> 1) + (uint32_t)r) + 2u * (uint32_t)(h & 1);
+      t->tab[mode][k] = (q << 16) | (area << 8) | where;
     }
   for (int i = 0; i < 22; i++)
     t->shift4[i] = (uint32_t)(kQuantShift[i][0] + 1) | (uint32_t)(kQuantShift[i][1] + 1) << 4 |

@@ -119,11 +119,12 @@ __device__ __forceinline__ IdctPK idct_pk_constants() {
   MIRTJ_PK_ADD(x7, t0, x1) /* y4 */                           \
   MIRTJ_PK_SUB(t0, t0, x1) /* y3 */
 
-// DESCALE (the +4 came in with DC), clamp to 16..235, and the two rows' pixels sorted into their dwords:
+// DESCALE (the +4 came in with DC), clamp to 16..235 (RTjpeg; the DV decoder passes 0 and 255 | 255 << 16: operands lo,
+// c235), and the two rows' pixels sorted into their dwords:
 // y0..y7 hold (row r | row r+1 << 16) of pixel columns 0..7; on exit y1, y5 = row r and y3, y7 = row r + 1
 #define MIRTJ_PK_PX1(Y)                                      \
   "v_pk_ashrrev_i16 " Y ", 3, " Y " op_sel_hi:[0,1]\n\t"     \
-  "v_pk_max_i16 " Y ", 16, " Y " op_sel_hi:[0,1]\n\t"        \
+  "v_pk_max_i16 " Y ", %[lo], " Y " op_sel_hi:[0,1]\n\t"     \
   "v_pk_min_i16 " Y ", " Y ", %[c235]\n\t"
 #define MIRTJ_PK_PX_PACK(y0, y1, y2, y3, y4, y5, y6, y7)                                                            \
   MIRTJ_PK_PX1(y0) MIRTJ_PK_PX1(y1) MIRTJ_PK_PX1(y2) MIRTJ_PK_PX1(y3) MIRTJ_PK_PX1(y4) MIRTJ_PK_PX1(y5)             \
@@ -168,6 +169,7 @@ __device__ __forceinline__ void idct8_pk_col(uint32_t (&x)[8], const IdctPK& K) 
 #define MIRTJ_PK_REGROUP(T, YA, YB)                                  \
   "v_perm_b32 " T ", " YB ", " YA ", %[sello]\n\t" /* even column */ \
   "v_perm_b32 " YB ", " YB ", " YA ", %[selhi]\n\t" /* odd column */
+template <int kLo = 16>  // the lower clamp (an inline constant); the upper one is K.c235
 __device__ __forceinline__ void idct8_pk_row_px(uint32_t (&ya)[4], uint32_t (&yb)[4], uint2& a, uint2& b,
                                                 const IdctPK& K) {
   uint32_t x0, x2, x4, x6;
@@ -181,7 +183,8 @@ __device__ __forceinline__ void idct8_pk_row_px(uint32_t (&ya)[4], uint32_t (&yb
       MIRTJ_PK_PX_PACK("%[x2]", "%[x3]", "%[x5]", "%[t0]", "%[x7]", "%[x0]", "%[x4]", "%[x6]")
       : [x0] "=&v"(x0), [x2] "=&v"(x2), [x4] "=&v"(x4), [x6] "=&v"(x6), [t0] "+v"(a0), [t1] "+v"(a1), [pl] "+v"(a2),
         [ph] "+v"(a3), [x1] "+v"(b0), [x3] "+v"(b1), [x5] "+v"(b2), [x7] "+v"(b3)
-      : MIRTJ_PK_OPERANDS, [selt] MIRTJ_KREG(K.sel_t), [sello] MIRTJ_KREG(K.sel_lo), [selhi] MIRTJ_KREG(K.sel_hi), [c235] "v"(K.c235));
+      : MIRTJ_PK_OPERANDS, [selt] MIRTJ_KREG(K.sel_t), [sello] MIRTJ_KREG(K.sel_lo), [selhi] MIRTJ_KREG(K.sel_hi), [c235] "v"(K.c235),
+        [lo] "n"(kLo));
   // MIRTJ_PK_PX_PACK leaves the rows in the registers of y1 y3 y5 y7 = x3 t0 x0 x6
   a = make_uint2(b1, x0);
   b = make_uint2(a0, x6);
@@ -243,7 +246,8 @@ __device__ __forceinline__ void idct8_pk_lo3_row_px(uint32_t ya0, uint32_t ya1, 
       MIRTJ_PK_PX_PACK("%[e0]", "%[e1]", "%[e2]", "%[a]", "%[b]", "%[x1]", "%[z]", "%[x0]")
       : [x0] "=&v"(x0), [a] "=&v"(a), [m] "=&v"(m), [z] "=&v"(z), [b] "=&v"(b), [e0] "=&v"(e0), [e1] "=&v"(e1),
         [e2] "=&v"(e2), [pl] "+v"(ya0), [x1] "+v"(ya1), [x2] "+v"(yb0), [ph] "+v"(yb1)
-      : MIRTJ_PK_OPERANDS, [selt] MIRTJ_KREG(K.sel_t), [sello] MIRTJ_KREG(K.sel_lo), [selhi] MIRTJ_KREG(K.sel_hi), [c235] "v"(K.c235));
+      : MIRTJ_PK_OPERANDS, [selt] MIRTJ_KREG(K.sel_t), [sello] MIRTJ_KREG(K.sel_lo), [selhi] MIRTJ_KREG(K.sel_hi), [c235] "v"(K.c235),
+        [lo] "n"(16));
   // rows in the registers of y1 y3 y5 y7 = e1 a x1 x0
   ra = make_uint2(e1, ya1);
   rb = make_uint2(a, x0);

@@ -122,7 +122,9 @@ def test_product_tables_are_what_the_statement_makes_of_the_format():
         D.lib().dvo_scan(mode, D.p8(sc))
         for k in range(64):
             e = int(t["tab"][mode, k])
-            assert e >> 16 == q[k] and (e & 255) == 2 * sc[k] and (e >> 8) & 3 == (0 if k < 6 else 1 if k < 21 else 2 if k < 43 else 3)
+            r, h = int(sc[k]) >> 3, int(sc[k]) & 7  # scratch: dword (column pair, row) at 8 * pair + row, the odd column in its high half
+            assert e >> 16 == q[k] and (e & 255) == 4 * (8 * (h >> 1) + r) + 2 * (h & 1)
+            assert (e >> 8) & 3 == (0 if k < 6 else 1 if k < 21 else 2 if k < 43 else 3)
     off = (6, 3, 0, 1)
     for qno in range(16):
         for cls in range(4):
