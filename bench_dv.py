@@ -113,8 +113,8 @@ def run(a, rank, world, gpu, dist, red_dev, shard, barrier, force_dist):
                             "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None, "alg_bytes_per_launch": alg,
                             "ms_per_launch": round(per, 4),
                             "note": "algorithmic bytes = DIF frame read once + picture written once (638,400 B per frame); the "
-                                    "kernel is bound by vector-instruction issue (bit-serial variable-length decode per block), "
-                                    "not by HBM: DESIGN.md section 9"},
+                                    "kernel is bound by vector-instruction issue (3,400 per wave of 60 blocks, three quarters of "
+                                    "them the three-pass variable-length decode), not by HBM: DESIGN.md section 9"},
                "parity_checked": rep.checked, "parity_mismatches": rep.mismatches,
                "parity_note": "against this repository's own CPU statement of the format (no DV pixel decoder exists in the "
                               "reference tree): unpinned"}

@@ -202,13 +202,16 @@ __global__ __launch_bounds__(64 * kDvWaves) void k_dv_decode(const uint8_t* __re
   const uint32_t sh4 = s_sh[qno + (cls == 0u ? 6u : cls == 1u ? 3u : cls == 2u ? 0u : 1u)] + (cls == 3u ? 0x1111u : 0u);
   const uint32_t tab_m = 64u * mode;
 
-  // a code word: its table entry from the next 16 bits (top of w)
+  // a code word: its table entry from the next 16 bits (top of w).  lut9 holds 0 for 11111....: the longer words
   auto lookup = [&](uint32_t w) -> uint32_t {
-    if ((w >> 27) != 31u) return s_lut9[w >> 23];
-    const uint32_t i7 = (w >> 20) & 127u;
-    if (i7 < 64u) return s_lut2[i7];
-    if (i7 < 96u) return vlc_entry(13u, ((w >> 19) & 63u) + 1u, 0u);  // 1111110 rrrrrr: a run of zeros (and one more)
-    return vlc_entry(16u, 1u, (w >> 17) & 255u);                       // 1111111 aaaaaaaa s
+    uint32_t e = s_lut9[w >> 23];
+    if (e == 0u) {
+      const uint32_t i7 = (w >> 20) & 127u;
+      e = i7 < 64u ? s_lut2[i7]
+          : i7 < 96u ? vlc_entry(13u, ((w >> 19) & 63u) + 1u, 0u)  // 1111110 rrrrrr: a run of zeros (and one more)
+                     : vlc_entry(16u, 1u, (w >> 17) & 255u);       // 1111111 aaaaaaaa s
+    }
+    return e;
   };
   uint32_t pos = 0;  // scan position of the coefficient decoded last; > 63: the block is finished
   auto apply = [&](uint32_t e, uint32_t w) {  // the word is complete: move on, store the coefficient
@@ -219,7 +222,9 @@ __global__ __launch_bounds__(64 * kDvWaves) void k_dv_decode(const uint8_t* __re
     const int level = (w >> (32u - len)) & 1u ? -(int)amp : (int)amp;
     const uint32_t t = s_tab[tab_m + pos];
     const uint32_t s = (sh4 >> (4u * ((t >> 8) & 3u))) & 15u;
-    *(int16_t*)(my + (t & 255u)) = (int16_t)((level * (int)((t >> 16) << s) + 8192) >> 14);
+    int prod;  // |level| <= 255, the multiplier below 2^22: the 24-bit multiplier is exact (and full rate)
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(prod) : "v"(level), "v"((int)((t >> 16) << s)), "v"(8192));
+    *(int16_t*)(my + (t & 255u)) = (int16_t)(prod >> 14);
   };
 
   // ---- pass 1: every block from its own area ----

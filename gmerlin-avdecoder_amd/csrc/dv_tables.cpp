@@ -67,6 +67,9 @@ bool build_tables(Tables* t) {
   kraft += 64ull << 2;
   kraft += 256ull;
   if (kraft != 1ull << 15) return false;
+  // (the kernels take a zero in the first table for "11111....: look in the second table or at the escape's own bits")
+  for (uint32_t i = 0; i < 512u; i++)
+    if ((t->lut9[i] == 0u) != (i >> 4 == 31u)) return false;
   // ---- reconstruction: multiplier, area, where the coefficient goes ----
   const double pi = 3.14159265358979323846;
   double cs[8], w[8], aan[8];

@@ -12,4 +12,4 @@ B="--no-cpu --no-e2e --no-sweep --no-stress --content hash"
 for amp in 8 24 32 40; do
 timeout -k 10 300 python bench.py $B --amp $amp --steps 6 --warmup 6 2>/dev/null | pr "amp$amp default" | cut -c1-400 | tee -a $O/amp_policy2.txt
 done
-bash tools/r4_job21.sh
+bash tools/jobs_r04/job21.sh

@@ -5,4 +5,4 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r4; mkdir -p $O
 timeout -k 10 600 python -m pytest tests/test_gpu_dv.py -m gpu -x -q > $O/pytest_dv.log 2>&1; echo "dv pytest rc=$?"; tail -15 $O/pytest_dv.log
 timeout -k 10 600 python -m pytest tests/test_gpu_overlap.py tests/test_plugin_harness.py -m gpu -x -q > $O/pytest_ov.log 2>&1; echo "overlap+harness pytest rc=$?"; tail -8 $O/pytest_ov.log
-bash tools/r4_job4.sh
+bash tools/jobs_r04/job4.sh
