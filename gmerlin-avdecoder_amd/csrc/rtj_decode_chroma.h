@@ -434,20 +434,25 @@ __device__ __forceinline__ void chroma_pool_wave(uint32_t* __restrict__ s_lds, c
 // nothing depends on which XCD a workgroup lands on.
 // ---------------------------------------------------------------------------------------
 constexpr uint32_t kXcds = 8;
+#ifndef MIRTJ_SPLIT_LUMA_SG
+#define MIRTJ_SPLIT_LUMA_SG 3
+#endif
+constexpr int kSplitLumaSuperGroups = MIRTJ_SPLIT_LUMA_SG;  // super groups a luma wave takes at most
 constexpr uint32_t kSplitXcdRot = 1;  // stripes move on by one XCD per frame (k_decode_split)
-// luma / chroma waves per XCD and frame: a luma wave takes up to six super groups (18 groups; round 3's waves took 11), a
-// chroma wave up to kPoolItersMax.  How many there are of each decides more than how long they run: with L + C EVEN the
-// launch is 2 ... 25 % slower than with the odd counts next to it (1080p x 16,384, C = 1: L = 3 17.8 ms, 4 16.2, 5 16.6,
-// 7 19.8, 8 16.4, 9 17.0, 10 16.5, 11 21.0, 12 16.4, 13 17.4; two chroma waves of half the length 23 ... 24 ms:
-// profiles/r04/split_waves_per_xcd.txt) — an XCD deals its workgroups to its 32 CUs in turn, and an even period puts the
-// chroma waves, which run longest, on a fraction of them.  So L is made to leave L + C odd.
+// luma / chroma waves per XCD and frame: a luma wave takes up to kSplitLumaSuperGroups super groups (9 groups; round 3's
+// waves took 11 with their chroma), a chroma wave up to kPoolItersMax.  How many there are of each decides more than how
+// long they run: with L + C EVEN the launch is 2 ... 25 % slower than with the odd counts next to it (1080p x 16,384, 11
+// super groups per XCD, C = 1: L = 2 16.4 ms, 3 17.8, 4 16.2, 5 16.6, 7 19.8, 8 16.4, 9 17.0, 10 16.5, 11 21.0, 12 16.4,
+// 13 17.4; two chroma waves of half the length 23 ... 24 ms: profiles/r04/split_waves_per_xcd.txt) — an XCD deals its
+// workgroups to its 32 CUs in turn, and an even period puts the chroma waves, which run longest, on a fraction of them.
+// So L is made to leave L + C odd.
 __host__ __device__ constexpr uint32_t split_chroma_waves(uint32_t groups) {
   const uint32_t sg = (groups + (uint32_t)kPoolGroups - 1u) / (uint32_t)kPoolGroups, per_xcd = (sg + kXcds - 1u) / kXcds;
   return per_xcd ? (per_xcd + (uint32_t)kPoolItersMax - 1u) / (uint32_t)kPoolItersMax : 1u;
 }
 __host__ __device__ constexpr uint32_t split_luma_waves(uint32_t groups) {
   const uint32_t sg = (groups + (uint32_t)kPoolGroups - 1u) / (uint32_t)kPoolGroups, per_xcd = (sg + kXcds - 1u) / kXcds;
-  const uint32_t lw = per_xcd ? (per_xcd + 5u) / 6u : 1u;
+  const uint32_t lw = per_xcd ? (per_xcd + (uint32_t)kSplitLumaSuperGroups - 1u) / (uint32_t)kSplitLumaSuperGroups : 1u;
   return ((lw + split_chroma_waves(groups)) & 1u) ? lw : lw + 1u;
 }
 __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode_split(const FrameDev* __restrict__ frames,
