@@ -200,7 +200,8 @@ def kernel_source_digest():
     hsh = hashlib.sha256()
     csrc = os.path.join(ROOT, "gmerlin-avdecoder_amd", "csrc")
     for name in sorted(os.listdir(csrc)):
-        if name.endswith((".h", ".hip", ".cpp")) and ("kernels" in name or "idct" in name or name == "rtj_common.h"):
+        if name.endswith((".h", ".hip", ".cpp")) and ("kernels" in name or "idct" in name or
+                                                       name in ("rtj_common.h", "rtj_decode_chroma.h")):
             hsh.update(name.encode())
             hsh.update(strip_comments(open(os.path.join(csrc, name), encoding="utf-8").read()).encode())
     # ... and the launch geometry (grids, spans, walkers per launch: what decides how often bytes are fetched), which

@@ -467,8 +467,7 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode_split(c
   __shared__ __attribute__((aligned(16))) uint32_t s_lds[kDecLdsWords];
   // (the stripe of super groups an XCD owns moves on by xcd_rot from frame to frame: every XCD gets every stripe in turn)
   const uint32_t x = (blockIdx.x + blockIdx.y * (xcd_rot & 7u)) % kXcds;
-  uint32_t r = blockIdx.x / kXcds;
-  if (xcd_rot & 256u) r = r < chroma_waves ? r + luma_waves : r - chroma_waves;  // (experiments: the chroma waves first)
+  const uint32_t r = blockIdx.x / kXcds;
   if (r < luma_waves)
     decode_wave<true, false, 2, true, true>(s_lds, frames, blockIdx.y, x + kXcds * r, kXcds * luma_waves, 0u, stream, lut,
                                             blkoff, outbuf, nullptr, list);
