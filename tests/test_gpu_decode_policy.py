@@ -172,3 +172,43 @@ def test_the_serial_walker_on_built_and_arbitrary_streams(monkeypatch):
     dev.free(d_stream)
     dev.free(d_out)
     dev.close()
+
+
+def test_launches_the_serial_walker_takes_never_try_the_longest_lead(monkeypatch):
+    """k_spec_policy: walkers with the 6,144-byte lead parse four times their chunk; where the to-do list of a launch goes
+    to the serial walker anyway (MI_RTJ_SERIAL_MIN <= packets of the launch) a plan whose 1,536-byte lead fails pauses the
+    speculation instead of trying it; launches the walker does not take (MI_RTJ_SERIAL_MIN = 0) still do.  Pictures as the
+    oracle's all along."""
+    monkeypatch.setenv("MI_RTJ_SPEC", "2")  # speculate whatever the batch size, with the policy
+    w, h = 320, 240
+    pkts = [R.OracleEncoder(w, h, 255).encode(R.synth_frame(w, h, i, seed=5, amp=64)) for i in range(16)]
+    fsz = T.frame_bytes(w, h)
+    want = []
+    for p in pkts:
+        o = np.zeros(fsz, np.uint8)
+        R.OracleDecoder().decode(p, o)
+        want.append(o)
+    seen = {}
+    for serial_min in ("4", "0"):
+        monkeypatch.setenv("MI_RTJ_SERIAL_MIN", serial_min)
+        dev = P.MiRtj()
+        d_stream, po, pl, hdrs = dev.upload_packets(pkts, align=1)
+        d_out = dev.alloc(fsz * len(pkts))
+        plan = dev.plan(hdrs, po, pl, np.arange(len(pkts), dtype=np.uint64) * np.uint64(fsz))
+        leads, paused = [], 0
+        for k in range(10):
+            leads.append(plan.spec_lead()[0])
+            paused += plan.spec_lead()[1] > 0
+            dev.memset(d_out, 0, fsz * len(pkts))
+            plan.decode(d_stream, d_out)
+            dev.sync()
+            for i in range(len(pkts)):
+                assert np.array_equal(dev.d2h(d_out, fsz, offset=i * fsz), want[i]), (serial_min, k, i)
+        seen[serial_min] = (leads, paused)
+        plan.close()
+        dev.free(d_stream)
+        dev.free(d_out)
+        dev.close()
+    assert 6144 not in seen["4"][0] and seen["4"][1] > 0, seen["4"]   # paused straight from the 1,536-byte lead
+    assert 1536 in seen["4"][0]
+    assert 6144 in seen["0"][0], seen["0"]                              # the longest lead was tried first
