@@ -108,6 +108,13 @@ struct mi_rtj_plan {
   // launch fits; two counters, launches alternate, a launch's k_decode_list zeroes the other one
   uint2* d_declist = nullptr;
   uint32_t* d_declist_cnt = nullptr;
+  // the policy's mode word as the host last saw it: pinned host memory that k_decode_list writes behind its books.  The
+  // host reads it without waiting (it may be launches old) for ONE decision: while it says "split form" the classic form's
+  // kernel is not enqueued at all (it would return at once: ~90 us of empty workgroups per 16,384 pictures) and
+  // k_decode_split is told to run whatever the device's word says — so a stale view costs time on content that just
+  // turned noisy, never pictures
+  uint32_t* h_mode_seen = nullptr;
+  uint32_t* d_mode_seen = nullptr;
   uint64_t declist_cap = 0;
   int declist_flip = 0;
   bool batch_seen = false;                 // a batch launch (a wave takes several parts of its groups, no previous picture) was queued
@@ -612,8 +619,17 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out, int what = kL
       if (!p->d_declist_cnt) {  // two list counters, then the policy's two words (mode, launches left in it)
         HIPCHK(c, hipMalloc((void**)&p->d_declist_cnt, 4 * sizeof(uint32_t)));
         HIPCHK(c, hipMemsetAsync(p->d_declist_cnt, 0, 4 * sizeof(uint32_t), ds));
+        if (hipHostMalloc((void**)&p->h_mode_seen, sizeof(uint32_t), hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer((void**)&p->d_mode_seen, p->h_mode_seen, 0) == hipSuccess) {
+          *p->h_mode_seen = 0xFFFFFFFFu;  // nothing seen yet: both forms are enqueued
+        } else {  // (no mapped host memory: both forms are enqueued on every launch, as before)
+          (void)hipGetLastError();
+          if (p->h_mode_seen) (void)hipHostFree(p->h_mode_seen);
+          p->h_mode_seen = p->d_mode_seen = nullptr;
+        }
       }
       uint32_t* const policy = p->split < 0 ? p->d_declist_cnt + 2 : nullptr;  // (forced split: no policy)
+      const bool split_seen = policy && p->h_mode_seen && *(volatile uint32_t*)p->h_mode_seen == (uint32_t)kDecModeSplit;
       const DecList list{p->d_declist_cnt + p->declist_flip, p->d_declist, (uint32_t)p->declist_cap};
       uint32_t lw = split_luma_waves(p->max_groups);
       uint32_t cw = split_chroma_waves(p->max_groups);
@@ -631,13 +647,14 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out, int what = kL
                              (const uint32_t*)nullptr, xrot);
       } else
       hipLaunchKernelGGL(k_decode_split, dim3(kXcds * (lw + cw), drows), block, 0, ds, dfr, st, c->d_lut, blk, out8, lw, cw,
-                         list, (const uint32_t*)policy, xrot);
-      // the classic form: runs while the policy says so (returns at once otherwise: ~30 us of empty workgroups)
-      if (policy)
+                         list, split_seen ? (const uint32_t*)nullptr : (const uint32_t*)policy, xrot);
+      // the classic form: runs while the policy says so (returns at once otherwise), and is not enqueued while the host
+      // has seen the policy in its split mode (h_mode_seen above)
+      if (policy && !split_seen)
         hipLaunchKernelGGL((k_decode<true, false>), grid, block, 0, ds, dfr, st, c->d_lut, blk, out8,
                            (const uint8_t*)nullptr, (const uint32_t*)policy);
       hipLaunchKernelGGL(k_decode_list, dim3(kDecListGrid), block, 0, ds, dfr, st, c->d_lut, blk, out8, list,
-                         p->d_declist_cnt + (p->declist_flip ^ 1), policy, (uint32_t)need);
+                         p->d_declist_cnt + (p->declist_flip ^ 1), policy, (uint32_t)need, policy ? p->d_mode_seen : nullptr);
       p->declist_flip ^= 1;
     } else if (span == 3u) {
       if (p->prev_pic)
@@ -936,6 +953,7 @@ void mi_rtj_plan_destroy(mi_rtj_plan* p) {
   if (p->d_blkoff_b) (void)hipFree(p->d_blkoff_b);
   if (p->d_declist) (void)hipFree(p->d_declist);
   if (p->d_declist_cnt) (void)hipFree(p->d_declist_cnt);
+  if (p->h_mode_seen) (void)hipHostFree(p->h_mode_seen);
   for (hipEvent_t e : p->e_read)
     if (e) (void)hipEventDestroy(e);
   delete p;

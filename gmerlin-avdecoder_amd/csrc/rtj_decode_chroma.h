@@ -485,7 +485,8 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode_list(co
                                                               const uint32_t* __restrict__ blkoff,
                                                               uint8_t* __restrict__ outbuf, const DecList list,
                                                               uint32_t* __restrict__ next_count,
-                                                              uint32_t* __restrict__ policy, const uint32_t parts_total) {
+                                                              uint32_t* __restrict__ policy, const uint32_t parts_total,
+                                                              uint32_t* __restrict__ mode_seen) {
   __shared__ __attribute__((aligned(16))) uint32_t s_lds[kDecLdsWords];
   uint32_t n = *list.count;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -500,6 +501,9 @@ __global__ __launch_bounds__(kDecThreads, MIRTJ_DEC_WAVES) void k_decode_list(co
       } else if (--policy[1] == 0u) {
         policy[0] = kDecModeSplit;
       }
+      // what the next launch will run, where the host can see it without waiting (pinned host memory; it decides whether
+      // the classic form's kernel is enqueued at all: mi_rtjpeg.hip, h_mode_seen)
+      if (mode_seen) __hip_atomic_store(mode_seen, policy[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
   n = n < list.cap ? n : list.cap;
