@@ -558,7 +558,7 @@ def main():
     # SURVEY.md section 8d's stress variant (noise +-64: 2.3 MB packets, nothing for the speculative index to lock on)
     # as a second, short, clearly labelled measurement; never part of `value`
     if world == 1 and rank == 0 and not a.no_stress and a.amp != 64:
-        ns_frames = n  # the headline launch size: its plan runs its kernels back to back, so kernels_ms are kernel costs
+        ns_frames = n  # the headline launch size
         # five warm-up launches: the plan's policy needs three to give the speculation up on this content (short lead lost,
         # long lead lost twice: k_spec_policy), after which the walkers return at once for 64 launches — the timed steps
         # are the steady state (round 2 timed one of the three and reported 93.6 K)
@@ -573,7 +573,12 @@ def main():
                                "note": "same code, noise amplitude 64 (SURVEY 8d stress variant), 5 timed steps after 5 warm-up "
                                        "launches: steady state — the speculative index paused by its policy, the packets indexed by the "
                                        "serial walker (launches of 4096 packets and more: its time is in the k_index_summarize slot) or "
-                                       "the exact kernels, k_decode in its classic form (decode_form 1)"}
+                                       "the exact kernels, k_decode in its classic form (decode_form 1); once the host has seen the decode policy "
+                                       "in that mode (a pinned word, read without waiting) a plan of this size builds the index of launch "
+                                       "k + 1 next to the transform of launch k, as smaller plans always do: kernels_ms are then times of "
+                                       "kernels that share the device, not kernel costs (MI_RTJ_OVERLAP=0 runs them back to back: "
+                                       "profiles/r04/overlap_at_16384.txt)",
+                               "index_overlaps_transform": s["plan"].overlapped()}
         s["plan"].close()
         dev.free(s["d_st"])
         dev.free(s["d_out"])

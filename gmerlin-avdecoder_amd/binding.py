@@ -29,7 +29,7 @@ EXPORTS = ["mi_rtj_device_count", "mi_rtj_create", "mi_rtj_destroy", "mi_rtj_las
            "mi_rtj_plan_decode", "mi_rtj_plan_info", "mi_rtj_plan_profile", "mi_rtj_plan_times",
            "mi_rtj_plan_read_index", "mi_rtj_synth_frames", "mi_rtj_synth_frames_lcg", "mi_rtj_encode_bound", "mi_rtj_encode_frames",
            "mi_rtj_get_tables", "mi_rtj_yuv420_to_rgb", "mi_rtj_encode_stream", "mi_rtj_decode_nocopy",
-           "mi_rtj_copy_ceiling", "mi_rtj_plan_spec_stats", "mi_rtj_plan_spec_lead", "mi_rtj_plan_decode_form",
+           "mi_rtj_copy_ceiling", "mi_rtj_plan_spec_stats", "mi_rtj_plan_spec_lead", "mi_rtj_plan_decode_form", "mi_rtj_plan_overlapped",
            "mi_rtj_plan_step_times", "mi_rtj_pipe_create", "mi_rtj_pipe_destroy", "mi_rtj_pipe_room",
            "mi_rtj_pipe_pending", "mi_rtj_pipe_submit", "mi_rtj_pipe_next", "mi_rtj_pipe_peek_tag", "mi_rtj_pipe_flush",
            "mi_rtj_pipe_profile", "mi_rtj_pipe_times"]
@@ -73,6 +73,7 @@ def load():
     L.mi_rtj_plan_spec_stats.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
     L.mi_rtj_plan_spec_lead.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mi_rtj_plan_decode_form.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
+    L.mi_rtj_plan_overlapped.argtypes = [vp]
     L.mi_rtj_plan_step_times.argtypes = [vp, C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int)]
     L.mi_rtj_pipe_create.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.mi_rtj_pipe_create.restype = vp
@@ -162,6 +163,10 @@ class Plan:
         form, left, listed = C.c_int(), C.c_int(), C.c_longlong()
         self.owner._chk(self.owner.L.mi_rtj_plan_decode_form(self.h, C.byref(form), C.byref(left), C.byref(listed)))
         return form.value, left.value, listed.value
+
+    def overlapped(self):
+        """True if the last decode built its index on the plan's own stream, next to the previous decode's transform."""
+        return bool(self.owner.L.mi_rtj_plan_overlapped(self.h))
 
     def spec_lead(self):
         """(bytes a walker parses before its chunk in the next decode, decodes left without speculation)."""

@@ -131,6 +131,13 @@ struct mi_rtj_plan {
   // vector-instruction issue, so a long launch gains nothing; a short one (1024 pictures: 6 rounds of resident waves
   // for k_decode, under one for the walkers) fills the other half's idle tails.  MI_RTJ_OVERLAP=0 / 1 overrides.
   bool overlap = false;
+  // Long launches (which do not overlap by default) of NOISY content do gain: there the index is the serial walker, heavy
+  // on the scalar unit, next to a transform heavy on the vector unit (+-32: 332 K against 297 K pictures per second at
+  // 16,384 per launch, +-64: 271 K against 251 K, profiles/r04/overlap_at_16384.txt).  The host knows such content by
+  // the decode policy's mode word (h_mode_seen: "classic form"), seen without waiting; while it says so the launches of
+  // a plan that may (overlap_dyn) run like an overlapped plan's, the second index and the stream made when first needed.
+  bool overlap_dyn = false;
+  bool last_overlapped = false;            // the launch before this one ran its index on own_idx
   hipStream_t own_idx = nullptr;
   uint32_t* d_blkoff_b = nullptr;          // the second block-offset index (d_blkoff is the first)
   hipEvent_t e_read[2] = {nullptr, nullptr};
@@ -444,16 +451,33 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out, int what = kL
   // The index kernels run on `is`, k_decode on the instance's stream.  Plans have them equal; a session gives its slots
   // an index stream of their own (p->idx_stream), so that the index of packet i + 1 is built while packet i — whose
   // picture the unchanged blocks of i + 1 come from — is still being transformed.
-  hipStream_t const ds = c->stream, is = p->idx_stream ? p->idx_stream : c->stream;
+  bool ov = p->overlap;
+  if (!ov && p->overlap_dyn && what == kLaunchAll && p->h_mode_seen &&
+      *(volatile uint32_t*)p->h_mode_seen == (uint32_t)kDecModeClassic) {
+    if (!p->d_blkoff_b && hipMalloc((void**)&p->d_blkoff_b, sizeof(uint32_t) * p->n_index) != hipSuccess) {
+      (void)hipGetLastError();  // no room for a second index: the plan stays as it was
+      p->d_blkoff_b = nullptr;
+      p->overlap_dyn = false;
+    }
+    if (p->overlap_dyn && !p->own_idx && hipStreamCreateWithFlags(&p->own_idx, hipStreamNonBlocking) != hipSuccess) {
+      (void)hipGetLastError();
+      p->own_idx = nullptr;
+      p->overlap_dyn = false;
+    }
+    ov = p->overlap_dyn;
+  }
+  hipStream_t const ds = c->stream, is = ov && !p->idx_stream ? p->own_idx : p->idx_stream ? p->idx_stream : c->stream;
   hipStream_t cur = is;
-  if (is != ds && c->input_dirty) {  // something queued on the instance's stream may still be writing the packets
+  // (a launch that overlaps behind one that did not: whatever the instance's stream still has queued — the last launch's
+  // transform reading the first index, the plan's descriptors on their way — comes first)
+  if (is != ds && (c->input_dirty || (ov && !p->overlap && !p->last_overlapped))) {  // something queued on the instance's stream may still be writing the packets
     if (!c->e_input) HIPCHK(c, hipEventCreateWithFlags(&c->e_input, hipEventDisableTiming));
     HIPCHK(c, hipEventRecord(c->e_input, ds));
     HIPCHK(c, hipStreamWaitEvent(is, c->e_input, 0));
   }
   c->input_dirty = false;
-  uint32_t* const blk = p->overlap && p->flip ? p->d_blkoff_b : p->d_blkoff;  // the index this launch writes and reads
-  if (p->overlap) {
+  uint32_t* const blk = ov && p->flip ? p->d_blkoff_b : p->d_blkoff;  // the index this launch writes and reads
+  if (ov) {
     // the launch before last read this index: its k_decode must be through with it
     if (p->e_read[p->flip]) HIPCHK(c, hipStreamWaitEvent(is, p->e_read[p->flip], 0));
     else HIPCHK(c, hipEventCreateWithFlags(&p->e_read[p->flip], hipEventDisableTiming));
@@ -674,11 +698,14 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out, int what = kL
   }
   if ((rc = end(MI_RTJ_K_DECODE)) != MI_RTJ_OK) return rc;
   HIPCHK(c, hipGetLastError());
-  if (p->overlap) {
+  if (ov) {
     HIPCHK(c, hipEventRecord(p->e_read[p->flip], ds));
     p->last = p->flip;
     p->flip ^= 1;
+  } else {
+    p->last = 0;
   }
+  if (what == kLaunchAll) p->last_overlapped = ov && is != ds;
   p->launches++;
   return MI_RTJ_OK;
 }
@@ -900,7 +927,8 @@ hipMalloc((void**)&p->d_blkoff, sizeof(uint32_t) * p->n_index) != hipSuccess) {
     // kernels that share the device cannot be timed one by one — the per-kernel figures of bench.py and rocprofv3 are
     // taken on launches that run their kernels back to back
     const uint64_t groups = (uint64_t)p->n * p->max_groups;
-    p->overlap = ov ? atoi(ov) != 0 : groups >= (uint64_t)kDecRotateMinGroups && groups < (uint64_t)kOverlapMaxGroups;
+    p->overlap = ov ? atoi(ov) == 1 : groups >= (uint64_t)kDecRotateMinGroups && groups < (uint64_t)kOverlapMaxGroups;
+    p->overlap_dyn = ov ? atoi(ov) == 2 : !p->overlap && groups >= (uint64_t)kOverlapMaxGroups;  // (2: tests, on small plans)
     if (p->overlap) {
       if (hipMalloc((void**)&p->d_blkoff_b, sizeof(uint32_t) * p->n_index) != hipSuccess ||
           hipStreamCreateWithFlags(&p->own_idx, hipStreamNonBlocking) != hipSuccess) {
@@ -1032,6 +1060,8 @@ int mi_rtj_plan_spec_lead(mi_rtj_plan* p, int* lead_bytes, int* paused_launches)
   return MI_RTJ_OK;
 }
 
+int mi_rtj_plan_overlapped(const mi_rtj_plan* p) { return p && p->last_overlapped ? 1 : 0; }
+
 int mi_rtj_plan_decode_form(mi_rtj_plan* p, int* form, int* classic_launches_left, long long* parts_listed) {
   if (!p || !form || !classic_launches_left || !parts_listed) return MI_RTJ_ERR_ARG;
   mi_rtj_ctx* c = p->ctx;
@@ -1090,7 +1120,7 @@ int mi_rtj_plan_read_index(mi_rtj_plan* p, uint32_t* dst, size_t max_entries) {
   mi_rtj_ctx* c = p->ctx;
   std::vector<uint32_t> all(p->n_index);
   HIPCHK(c, hipStreamSynchronize(c->stream));  // (k_decode of the last launch waited for its index)
-  HIPCHK(c, hipMemcpyAsync(all.data(), p->overlap && p->last ? p->d_blkoff_b : p->d_blkoff, sizeof(uint32_t) * p->n_index,
+  HIPCHK(c, hipMemcpyAsync(all.data(), p->last ? p->d_blkoff_b : p->d_blkoff, sizeof(uint32_t) * p->n_index,
                            hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   size_t k = 0;

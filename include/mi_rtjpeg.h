@@ -175,6 +175,11 @@ int mi_rtj_plan_spec_lead(mi_rtj_plan *plan, int *lead_bytes, int *paused_launch
  * *classic_launches_left = decodes left before the split form is tried again; *parts_listed = group parts the last
  * decode left to k_decode_list.  Synchronises the instance's stream. */
 int mi_rtj_plan_decode_form(mi_rtj_plan *plan, int *form, int *classic_launches_left, long long *parts_listed);
+/* 1 if the plan's last decode built its block index on the plan's own stream, next to the transform of the decode before
+ * it (plans of 129 .. 8191 pictures of 1080p always do; longer ones while the host has seen the decode policy in its
+ * classic mode, i.e. on noisy content; MI_RTJ_OVERLAP=0 / 1 / 2: never / always / by that rule whatever the size), else 0.
+ * Does not synchronise. */
+int mi_rtj_plan_overlapped(const mi_rtj_plan *plan);
 /* Test hook: copy the plan's block-start index (relative to each packet's first data byte,
  * nblocks+1 entries per frame, frames back to back) to the host after a decode. */
 int mi_rtj_plan_read_index(mi_rtj_plan *plan, uint32_t *dst, size_t max_entries);

@@ -84,3 +84,42 @@ def test_a_memset_queued_before_the_launch_is_seen_by_the_index_stream(dev):
     plan.close()
     dev.free(d_stream)
     dev.free(d_out)
+
+
+def test_a_long_plan_of_noisy_content_overlaps_once_the_host_has_seen_the_classic_mode(monkeypatch):
+    """Plans too long to overlap by default build the index of launch k + 1 next to the transform of launch k while the
+    host sees the decode policy in its classic mode (noisy content): the switch happens between launches of one plan,
+    both ways of running share the plan's first index, and pictures and index are the oracle's on every launch."""
+    import rtjlib as R
+    monkeypatch.setenv("MI_RTJ_ROTATE", "1")        # the batch launch shape (and with it the decode policy) for a small batch
+    monkeypatch.setenv("MI_RTJ_OVERLAP", "2")       # ... and the long plans' rule for this small one
+    monkeypatch.setenv("MI_RTJ_SPEC", "2")
+    w, h = 320, 240
+    for amp in (64, 2):  # noisy: the policy goes to the classic form and the plan starts to overlap; quiet: it never does
+        pkts = [R.OracleEncoder(w, h, 255).encode(R.synth_frame(w, h, i, seed=3, amp=amp)) for i in range(12)]
+        fsz = w * h * 3 // 2
+        want = []
+        for p in pkts:
+            o = np.zeros(fsz, np.uint8)
+            R.OracleDecoder().decode(p, o)
+            want.append(o)
+        nblk = (w // 16) * (h // 16) * 6
+        dev = P.MiRtj()
+        d_stream, po, pl, hdrs = dev.upload_packets(pkts, align=1)
+        d_out = dev.alloc(fsz * len(pkts))
+        plan = dev.plan(hdrs, po, pl, np.arange(len(pkts), dtype=np.uint64) * np.uint64(fsz))
+        for k in range(12):
+            dev.memset(d_out, 0, fsz * len(pkts))
+            plan.decode(d_stream, d_out)
+            if k % 3 == 2:  # (launches in a row without the host waiting in between, too)
+                dev.sync()
+                idx = plan.read_index()
+                for i, p in enumerate(pkts):
+                    assert np.array_equal(idx[i * (nblk + 1):(i + 1) * (nblk + 1)], R.OracleDecoder().block_offsets(p) - 12), (amp, k, i)
+                    assert np.array_equal(dev.d2h(d_out, fsz, offset=i * fsz), want[i]), (amp, k, i)
+        dev.sync()
+        assert plan.overlapped() == (amp == 64), (amp, plan.overlapped())
+        plan.close()
+        dev.free(d_stream)
+        dev.free(d_out)
+        dev.close()
