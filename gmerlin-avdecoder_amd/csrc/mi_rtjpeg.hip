@@ -135,7 +135,7 @@ struct mi_rtj_plan {
   // on the scalar unit, next to a transform heavy on the vector unit (+-32: 332 K against 297 K pictures per second at
   // 16,384 per launch, +-64: 271 K against 251 K, profiles/r04/overlap_at_16384.txt).  The host knows such content by
   // the decode policy's mode word (h_mode_seen: "classic form"), seen without waiting; while it says so the launches of
-  // a plan that may (overlap_dyn) run like an overlapped plan's, the second index and the stream made when first needed.
+  // a plan that may (overlap_dyn) run like an overlapped plan's; the second index and the stream are made with the plan.
   bool overlap_dyn = false;
   bool last_overlapped = false;            // the launch before this one ran its index on own_idx
   hipStream_t own_idx = nullptr;
@@ -454,17 +454,7 @@ int plan_launch(mi_rtj_plan* p, const void* d_stream, void* d_out, int what = kL
   bool ov = p->overlap;
   if (!ov && p->overlap_dyn && what == kLaunchAll && p->h_mode_seen &&
       *(volatile uint32_t*)p->h_mode_seen == (uint32_t)kDecModeClassic) {
-    if (!p->d_blkoff_b && hipMalloc((void**)&p->d_blkoff_b, sizeof(uint32_t) * p->n_index) != hipSuccess) {
-      (void)hipGetLastError();  // no room for a second index: the plan stays as it was
-      p->d_blkoff_b = nullptr;
-      p->overlap_dyn = false;
-    }
-    if (p->overlap_dyn && !p->own_idx && hipStreamCreateWithFlags(&p->own_idx, hipStreamNonBlocking) != hipSuccess) {
-      (void)hipGetLastError();
-      p->own_idx = nullptr;
-      p->overlap_dyn = false;
-    }
-    ov = p->overlap_dyn;
+    ov = true;  // (the second index and the stream were made with the plan: nothing is allocated on the launch path)
   }
   hipStream_t const ds = c->stream, is = ov && !p->idx_stream ? p->own_idx : p->idx_stream ? p->idx_stream : c->stream;
   hipStream_t cur = is;
@@ -937,6 +927,16 @@ hipMalloc((void**)&p->d_blkoff, sizeof(uint32_t) * p->n_index) != hipSuccess) {
         return nullptr;
       }
       p->idx_stream = p->own_idx;
+    } else if (p->overlap_dyn) {  // wanted, not needed: a plan without room for the second index stays as it was
+      if (hipMalloc((void**)&p->d_blkoff_b, sizeof(uint32_t) * p->n_index) != hipSuccess ||
+          hipStreamCreateWithFlags(&p->own_idx, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        if (p->d_blkoff_b) (void)hipFree(p->d_blkoff_b);
+        p->d_blkoff_b = nullptr;
+        if (p->own_idx) (void)hipStreamDestroy(p->own_idx);
+        p->own_idx = nullptr;
+        p->overlap_dyn = false;
+      }
     }
   }
   if (plan_upload(p) != MI_RTJ_OK) {
